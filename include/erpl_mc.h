@@ -1,0 +1,190 @@
+/*
+ * erpl_mc.h — C ABI of the MI355X-native Monte Carlo 6-DOF trajectory engine.
+ *
+ * The reference (smcconoughey/erpl_monte_carlo_sim) has NO native/FFI layer: its boundary for this
+ * path is two Python methods.  Each entry point below names the reference interface it replaces
+ * (file:line relative to the reference repo) and is what a ctypes/cffi stub added to the
+ * reference would bind.
+ *
+ *   erpl_mc_run_batch   <-  N x MonteCarloAnalyzer._run_single_simulation -> FlightSimulator.
+ *                           simulate_flight   (monte_carlo.py:225-306, simulator.py:127-293):
+ *                           launch rail (simulator.py:42-125) + RK4 loop (simulator.py:208-264)
+ *                           over _rocket_dynamics (simulator.py:295-460) + scalar results
+ *                           (simulator.py:488-494, :579-582)
+ *   erpl_config         <-  the attributes of Rocket (rocket.py:14-66), Solid/LiquidMotor
+ *                           (motor.py:15-52, :131-150), StandardAtmosphere (environment.py:13-24)
+ *                           and FlightSimulator (simulator.py:19-40) that the path reads
+ *   erpl_batch          <-  the per-sample objects _run_single_simulation builds
+ *                           (monte_carlo.py:228-288): perturbed IC, rocket masses, motor, wind
+ *
+ * Conventions: plain C, no C++ types, no exceptions across the boundary.  Every function returns
+ * 0 on success or a negative erpl_status; erpl_mc_last_error() gives a thread-local message.
+ * All per-sample arrays are structure-of-arrays: element (c, i) of a [C][n] array is at c*n + i.
+ * Device buffers are CALLER-OWNED (e.g. torch tensors); the library never frees or keeps them
+ * past completion of the work it enqueued on the given stream.
+ */
+#ifndef ERPL_MC_H
+#define ERPL_MC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ERPL_MC_ABI_VERSION 1
+
+#define ERPL_STATE_DIM 14   /* x y z vx vy vz q0(w) q1 q2 q3 wx wy wz propellant_fraction (simulator.py:130) */
+#define ERPL_IC_DIM 13      /* the same without propellant_fraction (always 1.0 at ignition, simulator.py:161) */
+#define ERPL_ROCKET_DIM 2   /* dry_mass, propellant_mass (monte_carlo.py:315-316) */
+#define ERPL_MOTOR_DIM 4    /* thrust, nozzle_exit_area, mass_flow_rate, burn_time */
+#define ERPL_SUMMARY_DIM 16
+#define ERPL_TRAJ_DIM 15    /* absolute time + 14 state */
+#define ERPL_MAX_MACH_KNOTS 16
+#define ERPL_MAX_CURVE_KNOTS 32
+#define ERPL_MAX_WIND_KNOTS 1024
+
+typedef enum erpl_status {
+  ERPL_OK = 0,
+  ERPL_ERR_INVALID = -1,   /* bad argument / shape / non-finite table */
+  ERPL_ERR_HIP = -2,       /* a HIP runtime call failed */
+  ERPL_ERR_NO_DEVICE = -3, /* no usable GPU: the product path never falls back to a CPU */
+  ERPL_ERR_CONFIG = -4     /* run_batch before set_config */
+} erpl_status;
+
+enum { ERPL_MOTOR_LIQUID = 0, ERPL_MOTOR_SOLID = 1 };
+enum { ERPL_PREC_F64 = 0, ERPL_PREC_F32 = 1 };
+
+/* erpl_batch.flags */
+enum {
+  ERPL_FLAG_STOP_AT_APOGEE = 1 /* extension (BASELINE config 2 "to apogee"): end a trajectory at the
+                                  first post-step state with z>1000 and vz<0 (simulator.py:247) */
+};
+
+/* rows of the per-sample summary, double [ERPL_SUMMARY_DIM][n] */
+enum {
+  ERPL_SUM_APOGEE_ALT = 0,     /* altitudes[argmax(altitudes)]  (simulator.py:488-490) incl. NaN-first rule */
+  ERPL_SUM_APOGEE_TIME = 1,    /* time[argmax] - rail_time */
+  ERPL_SUM_FIRST_APOGEE_ALT = 2,  /* max altitude up to the first-descent latch (simulator.py:247) */
+  ERPL_SUM_FIRST_APOGEE_TIME = 3,
+  ERPL_SUM_RANGE = 4,          /* sqrt(x_end^2 + y_end^2)  (simulator.py:493-494) */
+  ERPL_SUM_FLIGHT_TIME = 5,    /* t_end - rail_time        (simulator.py:582) */
+  ERPL_SUM_RAIL_EXIT_TIME = 6, /* simulator.py:104 */
+  ERPL_SUM_RAIL_EXIT_SPEED = 7,/* simulator.py:107 */
+  ERPL_SUM_IMPACT_X = 8,       /* final position */
+  ERPL_SUM_IMPACT_Y = 9,
+  ERPL_SUM_IMPACT_Z = 10,
+  ERPL_SUM_STEPS = 11,         /* RK4 steps taken */
+  ERPL_SUM_RAIL_EXIT_AOA = 12, /* simulator.py:121 */
+  ERPL_SUM_RAIL_EXIT_SIDESLIP = 13, /* simulator.py:122 */
+  ERPL_SUM_FINAL_VZ = 14,
+  ERPL_SUM_MAX_SPEED = 15      /* max |v| over rail-exit state + all steps (NaN ignored) */
+};
+
+/* per-sample int32 status word: low byte = why the RK4 loop ended, bits above = latches */
+enum {
+  ERPL_END_MAX_TIME = 0,  /* while t < max_time ran out       (simulator.py:216) */
+  ERPL_END_GROUND = 1,    /* z<=0.5 and vz<=0                 (simulator.py:238) */
+  ERPL_END_ALTITUDE = 2,  /* z>100 km                         (simulator.py:242) */
+  ERPL_END_COAST = 3,     /* coast time-out above 25 km       (simulator.py:260-264) */
+  ERPL_END_APOGEE = 4,    /* ERPL_FLAG_STOP_AT_APOGEE */
+  ERPL_ST_APOGEE_LATCHED = 1 << 8,
+  ERPL_ST_CHUTE = 1 << 9, /* parachute latch set (simulator.py:366-369) */
+  ERPL_ST_NAN = 1 << 10   /* altitude became NaN at some step */
+};
+
+/* Everything shared by all samples of a batch.  Plain attribute values of the reference objects;
+ * derived constants are computed inside the library exactly as the reference computes them. */
+typedef struct erpl_config {
+  /* Rocket (rocket.py:14-66) */
+  double diameter;                 /* rocket.py:16  (used for propellant Ixx, rocket.py:122) */
+  double center_of_mass_dry;       /* rocket.py:31 */
+  double Ixx_dry, Iyy_dry;         /* rocket.py:34-35  (Izz := Iyy, rocket.py:128) */
+  double reference_area;           /* rocket.py:39 */
+  double reference_diameter;       /* rocket.py:40 */
+  double cp_location;              /* rocket.py:56 (Barrowman, host-computed) */
+  double fin_root_chord, fin_tip_chord, fin_span, fin_sweep_angle; /* rocket.py:18-22 */
+  double parachute_area, parachute_cd, parachute_deployment_altitude; /* rocket.py:59-61 */
+  double power_off_drag_factor;    /* rocket.py:66 */
+  int32_t n_cd;                    /* Cd_data knots (rocket.py:43-47) */
+  int32_t n_cp;                    /* CP_shift_data knots (rocket.py:50-53) */
+  double cd_mach[ERPL_MAX_MACH_KNOTS], cd0[ERPL_MAX_MACH_KNOTS], cda[ERPL_MAX_MACH_KNOTS];
+  double cp_mach[ERPL_MAX_MACH_KNOTS], cp_shift[ERPL_MAX_MACH_KNOTS];
+  /* Motor, shared part (motor.py) */
+  int32_t motor_kind;              /* ERPL_MOTOR_LIQUID | ERPL_MOTOR_SOLID */
+  int32_t n_curve;                 /* solid thrust-curve knots (motor.py:31-41); 0 for liquid */
+  double curve_time[ERPL_MAX_CURVE_KNOTS];
+  double curve_thrust[ERPL_MAX_CURVE_KNOTS]; /* UNSCALED; per-sample thrust multiplies it (motor.py:105) */
+  /* StandardAtmosphere (environment.py:13-24) */
+  double sea_level_pressure, sea_level_temperature, temperature_lapse_rate;
+  double gas_constant, gravity;
+  double troposphere_height, stratosphere_height, stratosphere_temp;
+  /* FlightSimulator (simulator.py:19-40, :42, :209) */
+  double dt_initial;               /* rail step; flight step = min(dt_initial, 0.005) */
+  double max_time;
+  double rail_length;              /* 18.288 default argument (simulator.py:42) */
+  double pitch_damping, yaw_damping;
+} erpl_config;
+
+/* One batch of independent samples (device pointers for erpl_mc_run_batch). */
+typedef struct erpl_batch {
+  int64_t n;             /* samples */
+  int32_t precision;     /* ERPL_PREC_F64 (gate) | ERPL_PREC_F32 (throughput) */
+  int32_t k_wind;        /* wind knots; 0 = no profile -> zero wind (simulator.py:333-338) */
+  int32_t flags;
+  int32_t reserved;
+  const double* ic;      /* [13][n]  position, velocity, quaternion (w,x,y,z), angular velocity */
+  const double* rocket;  /* [2][n]   dry_mass, propellant_mass */
+  const double* motor;   /* [4][n]   thrust (liquid: thrust_vacuum [N]; solid: curve multiplier),
+                                     nozzle_exit_area, mass_flow_rate, burn_time */
+  const double* alt_grid;/* [k_wind] shared altitude knots, strictly increasing */
+  const void* wind;      /* [k_wind][3][n] per-sample u,v,w; double if F64, float if F32 */
+} erpl_batch;
+
+/* Outputs (device pointers).  traj_* are optional (NULL / 0 to disable): state history of a
+ * caller-chosen subset, replacing the per-step lists of simulator.py:212-231. */
+typedef struct erpl_out {
+  double* summary;        /* [ERPL_SUMMARY_DIM][n] */
+  int32_t* status;        /* [n] */
+  int64_t n_traj;         /* samples to record */
+  const int64_t* traj_ids;/* [n_traj] sample indices (device) */
+  int64_t traj_stride;    /* record every traj_stride-th step (step 0 = rail-exit state, last step always) */
+  int64_t traj_cap;       /* records per sample */
+  double* traj;           /* [n_traj][traj_cap][ERPL_TRAJ_DIM] */
+  int64_t* traj_len;      /* [n_traj] records written */
+} erpl_out;
+
+typedef struct erpl_ctx erpl_ctx;
+
+int erpl_mc_abi_version(void);
+const char* erpl_mc_last_error(void);
+
+/* One context per GPU (one host thread / torch.distributed rank each).  Calls on one context are
+ * serialised by the caller. */
+int erpl_mc_create(int device, erpl_ctx** out);
+int erpl_mc_destroy(erpl_ctx* ctx);
+
+/* Copies and validates cfg, derives the interval tables and uploads them. */
+int erpl_mc_set_config(erpl_ctx* ctx, const erpl_config* cfg);
+
+/* Grows the context workspace for batches of up to n samples (hipMalloc happens here, never in
+ * run_batch once the workspace is large enough, so run_batch is graph-capturable). */
+int erpl_mc_reserve(erpl_ctx* ctx, int64_t n);
+
+/* Enqueues rail phase + flight integration + summaries for the batch on `hip_stream`
+ * (a hipStream_t passed as void*; NULL = the default stream).  Asynchronous. */
+int erpl_mc_run_batch(erpl_ctx* ctx, const erpl_batch* batch, const erpl_out* out, void* hip_stream);
+
+/* Launch geometry knobs (tuning / tests): threads per workgroup, max resident workgroups for the
+ * persistent flight kernel (0 = library default), lane-refill threshold. */
+int erpl_mc_set_launch(erpl_ctx* ctx, int block_threads, int max_blocks, int refill_threshold);
+
+/* Diagnostics of the last run_batch on this ctx (after the stream has been synchronised):
+ * total RK4 steps integrated over all samples and total wave-iterations executed. */
+int erpl_mc_last_stats(erpl_ctx* ctx, double* total_steps, double* wave_iterations);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ERPL_MC_H */

@@ -1,0 +1,146 @@
+"""ctypes wrapper of oracle/liberpl_oracle.so (CPU restatement).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from erpl_monte_carlo_sim_amd import _abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "liberpl_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(os.path.join(HERE, "erpl_oracle.c")):
+        subprocess.run(["make", "-C", HERE, "-B" if force else "-s"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(SO)
+        dp = C.POINTER(C.c_double)
+        L.erpl_oracle_interp.restype = C.c_double
+        L.erpl_oracle_interp.argtypes = [C.c_double, dp, dp, C.c_int]
+        L.erpl_oracle_gravity.restype = C.c_double
+        L.erpl_oracle_gravity.argtypes = [C.POINTER(_abi.ErplConfig), C.c_double]
+        L.erpl_oracle_atmosphere.argtypes = [C.POINTER(_abi.ErplConfig), C.c_double, dp]
+        L.erpl_oracle_mass_props.argtypes = [C.POINTER(_abi.ErplConfig), C.c_double, C.c_double, C.c_double, dp]
+        L.erpl_oracle_aero.argtypes = [C.POINTER(_abi.ErplConfig), C.c_double, C.c_double, C.c_double,
+                                       C.c_double, C.c_int, dp]
+        L.erpl_oracle_run_batch.argtypes = [C.POINTER(_abi.ErplConfig), C.POINTER(_abi.ErplBatch),
+                                            C.POINTER(_abi.ErplOut), C.c_int]
+        L.erpl_oracle_rhs.argtypes = [C.POINTER(_abi.ErplConfig), C.POINTER(_abi.ErplBatch), C.c_double,
+                                      dp, C.POINTER(C.c_int), dp]
+        L.erpl_oracle_wind.argtypes = [C.POINTER(_abi.ErplBatch), C.c_double, dp]
+        L.erpl_oracle_motor.argtypes = [C.POINTER(_abi.ErplConfig), C.POINTER(_abi.ErplBatch), C.c_double,
+                                        C.c_double, dp]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def host_batch_struct(hb, flags=0):
+    """ErplBatch pointing at a HostBatch's NumPy arrays (kept alive by the caller)."""
+    for name in ("ic", "rocket", "motor", "alt_grid", "wind"):
+        a = getattr(hb, name)
+        if not (a.flags["C_CONTIGUOUS"] and a.dtype == np.float64):
+            setattr(hb, name, np.ascontiguousarray(a, dtype=np.float64))
+    b = _abi.ErplBatch()
+    b.n, b.precision, b.k_wind, b.flags = hb.n, _abi.PREC_F64, hb.k_wind, flags
+    b.ic, b.rocket, b.motor = _ptr(hb.ic), _ptr(hb.rocket), _ptr(hb.motor)
+    b.alt_grid = _ptr(hb.alt_grid) if hb.k_wind else None
+    b.wind = _ptr(hb.wind) if hb.k_wind else None
+    return b
+
+
+def run_batch(cfg, hb, flags=0, threads=0, traj_ids=None, traj_stride=1, traj_cap=0):
+    """-> (summary [16, n] float64, status [n] int32[, traj, traj_len])."""
+    L = lib()
+    b = host_batch_struct(hb, flags)
+    summary = np.zeros((_abi.SUMMARY_DIM, hb.n))
+    status = np.zeros(hb.n, dtype=np.int32)
+    o = _abi.ErplOut()
+    o.summary, o.status = _ptr(summary), _ptr(status)
+    traj = tlen = None
+    if traj_ids is not None and len(traj_ids):
+        ids = np.ascontiguousarray(traj_ids, dtype=np.int64)
+        traj = np.full((len(ids), traj_cap, _abi.TRAJ_DIM), np.nan)
+        tlen = np.zeros(len(ids), dtype=np.int64)
+        o.n_traj, o.traj_ids, o.traj_stride, o.traj_cap = len(ids), _ptr(ids), traj_stride, traj_cap
+        o.traj, o.traj_len = _ptr(traj), _ptr(tlen)
+    rc = L.erpl_oracle_run_batch(C.byref(cfg), C.byref(b), C.byref(o), threads)
+    if rc != 0:
+        raise RuntimeError(f"oracle run_batch rc={rc}")
+    if traj is not None:
+        return summary, status, traj, tlen
+    return summary, status
+
+
+def threads():
+    return lib().erpl_oracle_threads()
+
+
+def atmosphere(cfg, h):
+    out = np.zeros(4)
+    lib().erpl_oracle_atmosphere(C.byref(cfg), h, _dp(out))
+    return out
+
+
+def gravity(cfg, h):
+    return lib().erpl_oracle_gravity(C.byref(cfg), h)
+
+
+def mass_props(cfg, dry, prop, pf):
+    out = np.zeros(5)
+    lib().erpl_oracle_mass_props(C.byref(cfg), dry, prop, pf, _dp(out))
+    return out
+
+
+def aero(cfg, mach, alpha, beta, cg, power_on):
+    out = np.zeros(7)
+    lib().erpl_oracle_aero(C.byref(cfg), mach, alpha, beta, cg, int(power_on), _dp(out))
+    return out
+
+
+def interp(x, xp, fp):
+    xp = np.ascontiguousarray(xp, dtype=np.float64)
+    fp = np.ascontiguousarray(fp, dtype=np.float64)
+    return lib().erpl_oracle_interp(x, _dp(xp), _dp(fp), len(xp))
+
+
+def rhs(cfg, hb, t, state, chute):
+    b = host_batch_struct(hb)
+    st = np.ascontiguousarray(state, dtype=np.float64)
+    d = np.zeros(14)
+    ch = C.c_int(int(chute))
+    lib().erpl_oracle_rhs(C.byref(cfg), C.byref(b), t, _dp(st), C.byref(ch), _dp(d))
+    return d, ch.value
+
+
+def wind(hb, h):
+    b = host_batch_struct(hb)
+    w = np.zeros(3)
+    lib().erpl_oracle_wind(C.byref(b), h, _dp(w))
+    return w
+
+
+def motor(cfg, hb, t, p):
+    b = host_batch_struct(hb)
+    out = np.zeros(3)
+    lib().erpl_oracle_motor(C.byref(cfg), C.byref(b), t, p, _dp(out))
+    return out
