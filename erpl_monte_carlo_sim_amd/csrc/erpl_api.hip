@@ -1,0 +1,301 @@
+// erpl_api.hip — host side of the C ABI declared in include/erpl_mc.h.
+// Derives the device tables from erpl_config with the reference's own expressions (glibc libm,
+// the same pow/exp CPython uses), owns the per-GPU workspace and enqueues the two kernels.
+// There is deliberately no CPU execution path in this library.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <thread>
+#include <vector>
+
+#include "erpl_tables.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) return fail(ERPL_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+bool finite_all(const double* v, int n) {
+  for (int i = 0; i < n; ++i) if (!std::isfinite(v[i])) return false;
+  return true;
+}
+bool increasing(const double* v, int n) {
+  for (int i = 1; i < n; ++i) if (!(v[i] > v[i - 1])) return false;
+  return true;
+}
+
+// np.interp interval record of table (xp, fp, n) for abscissae in [u, next union knot)
+void interval_record(const double* xp, const double* fp, int n, bool below_all, double u,
+                     double& x0, double& y0, double& s) {
+  if (below_all || u < xp[0]) { x0 = xp[0]; y0 = fp[0]; s = 0.0; return; }
+  if (u >= xp[n - 1]) { x0 = xp[n - 1]; y0 = fp[n - 1]; s = 0.0; return; }
+  int j = 0;
+  while (j + 1 < n && xp[j + 1] <= u) ++j;
+  x0 = xp[j]; y0 = fp[j];
+  s = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);  // numpy arr_interp slope
+}
+
+template <typename R>
+void convert_scalars(const ErplScalars<double>& a, ErplScalars<R>& b) {
+#define X(name) b.name = (R)a.name;
+  ERPL_SCALARS(X)
+#undef X
+}
+
+int build_tables(const erpl_config& c, ErplTables& T) {
+  memset(&T, 0, sizeof(T));
+  if (c.n_cd < 1 || c.n_cd > ERPL_MAX_MACH_KNOTS || c.n_cp < 1 || c.n_cp > ERPL_MAX_MACH_KNOTS)
+    return fail(ERPL_ERR_INVALID, "Mach table sizes out of range (n_cd=%d n_cp=%d)", c.n_cd, c.n_cp);
+  if (!finite_all(c.cd_mach, c.n_cd) || !finite_all(c.cd0, c.n_cd) || !finite_all(c.cda, c.n_cd) ||
+      !finite_all(c.cp_mach, c.n_cp) || !finite_all(c.cp_shift, c.n_cp))
+    return fail(ERPL_ERR_INVALID, "non-finite aerodynamic table entry");
+  if (!increasing(c.cd_mach, c.n_cd) || !increasing(c.cp_mach, c.n_cp))
+    return fail(ERPL_ERR_INVALID, "Mach knots must be strictly increasing");
+  if (c.motor_kind != ERPL_MOTOR_LIQUID && c.motor_kind != ERPL_MOTOR_SOLID)
+    return fail(ERPL_ERR_INVALID, "unknown motor_kind %d", c.motor_kind);
+  if (c.motor_kind == ERPL_MOTOR_SOLID) {
+    if (c.n_curve < 1 || c.n_curve > ERPL_MAX_CURVE_KNOTS)
+      return fail(ERPL_ERR_INVALID, "thrust curve size out of range (%d)", c.n_curve);
+    if (!finite_all(c.curve_time, c.n_curve) || !finite_all(c.curve_thrust, c.n_curve) ||
+        !increasing(c.curve_time, c.n_curve))
+      return fail(ERPL_ERR_INVALID, "thrust curve must be finite with increasing time");
+  }
+  if (!(c.dt_initial > 0) || !std::isfinite(c.dt_initial) || !std::isfinite(c.max_time))
+    return fail(ERPL_ERR_INVALID, "dt_initial must be positive and finite");
+
+  ErplScalars<double>& s = T.s64;
+  s.dq2 = pow(c.diameter / 4, 2.0);                    // rocket.py:122
+  s.cg_dry = c.center_of_mass_dry;
+  s.prop_cg = c.center_of_mass_dry - 0.5;              // rocket.py:116
+  s.third = 4.0 / 12;                                  // rocket.py:121-123
+  s.Ixx_dry = c.Ixx_dry; s.Iyy_dry = c.Iyy_dry;
+  s.ref_area = c.reference_area; s.ref_diam = c.reference_diameter; s.cp_location = c.cp_location;
+  const double fin_area = 0.5 * (c.fin_root_chord + c.fin_tip_chord) * c.fin_span;  // rocket.py:176
+  s.AR = (fin_area > 0) ? 2 * pow(c.fin_span, 2.0) / fin_area : 0.0;                // rocket.py:177
+  s.two_pi_AR = 2 * M_PI * s.AR;                                                   // rocket.py:180
+  s.cos_sweep = cos(c.fin_sweep_angle);
+  s.cos_sweep_c = (1e-6 > s.cos_sweep) ? 1e-6 : s.cos_sweep;                        // rocket.py:179
+  s.AR_over_cos = s.AR / s.cos_sweep_c;
+  s.stall_angle = 15.0 * (M_PI / 180.0);                                           // rocket.py:167-168
+  s.max_angle = 45.0 * (M_PI / 180.0);
+  s.inv_stall_span = 1.0 / (s.max_angle - s.stall_angle);
+  s.chute_area = c.parachute_area; s.chute_cd = c.parachute_cd;
+  s.chute_alt = c.parachute_deployment_altitude; s.power_off = c.power_off_drag_factor;
+  s.P0 = c.sea_level_pressure; s.T0 = c.sea_level_temperature; s.lapse = c.temperature_lapse_rate;
+  s.Rg = c.gas_constant; s.g0 = c.gravity; s.h_tropo = c.troposphere_height;
+  s.h_strat = c.stratosphere_height; s.T_strat = c.stratosphere_temp;
+  s.tropo_exp = c.gravity / (c.gas_constant * c.temperature_lapse_rate);           // environment.py:33
+  s.p11 = c.sea_level_pressure * pow(c.stratosphere_temp / c.sea_level_temperature, s.tropo_exp);
+  s.p20 = s.p11 * exp(-c.gravity * (c.stratosphere_height - c.troposphere_height) /
+                      (c.gas_constant * c.stratosphere_temp));                     // environment.py:56-62
+  s.p25 = s.p20 * exp(-c.gravity * 5000.0 / (c.gas_constant * c.stratosphere_temp)); // :72-75
+  s.grad_exp = c.gravity / (c.gas_constant * 0.0028);                              // :81
+  s.dt_rail = c.dt_initial;
+  s.dt_flight = (0.005 < c.dt_initial) ? 0.005 : c.dt_initial;                     // simulator.py:209
+  s.half_dt = 0.5 * s.dt_flight;
+  s.dt_sixth = s.dt_flight / 6.0;
+  s.max_time = c.max_time; s.rail_length = c.rail_length;
+  s.pitch_damping = c.pitch_damping; s.yaw_damping = c.yaw_damping;
+  convert_scalars(T.s64, T.s32);
+  T.dt_rail = s.dt_rail; T.dt_flight = s.dt_flight; T.max_time = s.max_time;
+  T.motor_kind = c.motor_kind;
+  T.n_curve = (c.motor_kind == ERPL_MOTOR_SOLID) ? c.n_curve : 0;
+  for (int i = 0; i < T.n_curve; ++i) { T.curve_t[i] = c.curve_time[i]; T.curve_f[i] = c.curve_thrust[i]; }
+
+  // union of the Cd and CP-shift Mach knots and the per-interval np.interp records
+  std::vector<double> u(c.cd_mach, c.cd_mach + c.n_cd);
+  u.insert(u.end(), c.cp_mach, c.cp_mach + c.n_cp);
+  std::sort(u.begin(), u.end());
+  u.erase(std::unique(u.begin(), u.end()), u.end());
+  T.n_union = (int)u.size();
+  for (int i = 0; i < T.n_union; ++i) T.union_knots[i] = u[i];
+  for (int i = 0; i <= T.n_union; ++i) {
+    double* r = &T.mach_rec[i * ERPL_MACH_REC];
+    const bool below = (i == 0);
+    const double left = below ? u[0] : u[i - 1];
+    double x0, y0, sl;
+    interval_record(c.cd_mach, c.cd0, c.n_cd, below, left, x0, y0, sl);
+    r[0] = x0; r[1] = y0; r[2] = sl;
+    interval_record(c.cd_mach, c.cda, c.n_cd, below, left, x0, y0, sl);
+    r[3] = y0; r[4] = sl;
+    interval_record(c.cp_mach, c.cp_shift, c.n_cp, below, left, x0, y0, sl);
+    r[5] = x0; r[6] = y0; r[7] = sl;
+  }
+
+  // NaN fast-forward table (see erpl_tables.h): final t and step count of
+  // `t = sum_r dt_rail; while t < max_time: t += dt_flight` per rail-iteration count r.
+  T.n_coast = 0;
+  const double est = (c.max_time > 0) ? c.max_time / s.dt_flight : 0;
+  if (est < 2.0e6) {
+    std::vector<double> t0(ERPL_COAST_TABLE);
+    double t = 0.0;
+    for (int r = 0; r < ERPL_COAST_TABLE; ++r) { t0[r] = t; t += s.dt_rail; }
+    const int nthr = 8;
+    std::vector<std::thread> pool;
+    const double dtf = s.dt_flight, tmax = c.max_time;
+    for (int w = 0; w < nthr; ++w) {
+      pool.emplace_back([&, w]() {
+        for (int r = w; r < ERPL_COAST_TABLE; r += nthr) {
+          double tt = t0[r];
+          int32_t steps = 0;
+          while (tt < tmax) { tt += dtf; ++steps; }
+          T.coast_t[r] = tt;
+          T.coast_steps[r] = steps;
+        }
+      });
+    }
+    for (auto& th : pool) th.join();
+    T.n_coast = ERPL_COAST_TABLE;
+  }
+  return ERPL_OK;
+}
+
+}  // namespace
+
+struct erpl_ctx {
+  int device = 0;
+  int n_cu = 256;
+  bool has_cfg = false;
+  ErplTables* d_tables = nullptr;
+  void* ws_state = nullptr;
+  double* ws_t = nullptr;
+  int32_t* ws_nrail = nullptr;
+  int64_t cap = 0;
+  unsigned long long* d_counters = nullptr;
+  int block = 256, max_blocks = 0, refill = 8;
+};
+
+extern "C" {
+
+int erpl_mc_abi_version(void) { return ERPL_MC_ABI_VERSION; }
+const char* erpl_mc_last_error(void) { return g_err; }
+
+int erpl_mc_create(int device, erpl_ctx** out) {
+  if (!out) return fail(ERPL_ERR_INVALID, "out is NULL");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(ERPL_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+  if (device < 0 || device >= count) return fail(ERPL_ERR_INVALID, "device %d out of range (%d)", device, count);
+  HIP_TRY(hipSetDevice(device));
+  erpl_ctx* c = new erpl_ctx();
+  c->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+  hipError_t e = hipMalloc((void**)&c->d_tables, sizeof(ErplTables));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, 4 * sizeof(unsigned long long));
+  if (e != hipSuccess) { delete c; return fail(ERPL_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+  *out = c;
+  return ERPL_OK;
+}
+
+int erpl_mc_destroy(erpl_ctx* c) {
+  if (!c) return ERPL_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipFree(c->d_tables); (void)hipFree(c->d_counters);
+  (void)hipFree(c->ws_state); (void)hipFree(c->ws_t); (void)hipFree(c->ws_nrail);
+  delete c;
+  return ERPL_OK;
+}
+
+int erpl_mc_set_config(erpl_ctx* c, const erpl_config* cfg) {
+  if (!c || !cfg) return fail(ERPL_ERR_INVALID, "NULL argument");
+  static thread_local ErplTables T;
+  int rc = build_tables(*cfg, T);
+  if (rc != ERPL_OK) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpy(c->d_tables, &T, sizeof(T), hipMemcpyHostToDevice));
+  c->has_cfg = true;
+  return ERPL_OK;
+}
+
+int erpl_mc_reserve(erpl_ctx* c, int64_t n) {
+  if (!c || n < 0) return fail(ERPL_ERR_INVALID, "bad argument");
+  if (n <= c->cap) return ERPL_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  (void)hipFree(c->ws_state); (void)hipFree(c->ws_t); (void)hipFree(c->ws_nrail);
+  c->ws_state = nullptr; c->ws_t = nullptr; c->ws_nrail = nullptr; c->cap = 0;
+  HIP_TRY(hipMalloc(&c->ws_state, (size_t)n * ERPL_STATE_DIM * sizeof(double)));
+  HIP_TRY(hipMalloc((void**)&c->ws_t, (size_t)n * sizeof(double)));
+  HIP_TRY(hipMalloc((void**)&c->ws_nrail, (size_t)n * sizeof(int32_t)));
+  c->cap = n;
+  return ERPL_OK;
+}
+
+int erpl_mc_set_launch(erpl_ctx* c, int block_threads, int max_blocks, int refill_threshold) {
+  if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
+  if (block_threads != 64 && block_threads != 128 && block_threads != 256)
+    return fail(ERPL_ERR_INVALID, "block_threads must be 64, 128 or 256");
+  if (refill_threshold < 1 || refill_threshold > 64) return fail(ERPL_ERR_INVALID, "refill_threshold must be 1..64");
+  c->block = block_threads;
+  c->max_blocks = max_blocks < 0 ? 0 : max_blocks;
+  c->refill = refill_threshold;
+  return ERPL_OK;
+}
+
+int erpl_mc_run_batch(erpl_ctx* c, const erpl_batch* b, const erpl_out* o, void* stream) {
+  if (!c || !b || !o) return fail(ERPL_ERR_INVALID, "NULL argument");
+  if (!c->has_cfg) return fail(ERPL_ERR_CONFIG, "erpl_mc_set_config has not been called");
+  if (b->n < 0) return fail(ERPL_ERR_INVALID, "negative batch size");
+  if (b->n == 0) return ERPL_OK;
+  if (b->precision != ERPL_PREC_F64 && b->precision != ERPL_PREC_F32)
+    return fail(ERPL_ERR_INVALID, "unknown precision %d", b->precision);
+  if (b->k_wind < 0 || b->k_wind > ERPL_MAX_WIND_KNOTS)
+    return fail(ERPL_ERR_INVALID, "k_wind %d out of range 0..%d", b->k_wind, ERPL_MAX_WIND_KNOTS);
+  if (!b->ic || !b->rocket || !b->motor) return fail(ERPL_ERR_INVALID, "NULL input buffer");
+  if (b->k_wind > 0 && (!b->alt_grid || !b->wind)) return fail(ERPL_ERR_INVALID, "k_wind > 0 but no wind buffers");
+  if (!o->summary || !o->status) return fail(ERPL_ERR_INVALID, "NULL output buffer");
+  if (o->n_traj < 0 || (o->n_traj > 0 && (!o->traj_ids || !o->traj || !o->traj_len || o->traj_cap < 1 || o->traj_stride < 1)))
+    return fail(ERPL_ERR_INVALID, "inconsistent trajectory-capture arguments");
+  HIP_TRY(hipSetDevice(c->device));
+  if (b->n > c->cap) {
+    int rc = erpl_mc_reserve(c, b->n);
+    if (rc != ERPL_OK) return rc;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), st));
+  ErplKArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n = b->n; a.k_wind = b->k_wind; a.flags = b->flags;
+  a.ic = b->ic; a.rocket = b->rocket; a.motor = b->motor; a.alt_grid = b->alt_grid; a.wind = b->wind;
+  a.summary = o->summary; a.status = o->status;
+  a.ws_state = c->ws_state; a.ws_t = c->ws_t; a.ws_nrail = c->ws_nrail;
+  a.n_traj = o->n_traj; a.traj_stride = o->traj_stride; a.traj_cap = o->traj_cap;
+  a.traj_ids = o->traj_ids; a.traj = o->traj; a.traj_len = o->traj_len;
+  a.tables = c->d_tables;
+  a.counters = c->d_counters;
+  a.refill_threshold = c->refill;
+  const int max_blocks = c->max_blocks > 0 ? c->max_blocks : c->n_cu * 8;
+  int rc = (b->precision == ERPL_PREC_F64) ? erpl_launch_f64(a, c->block, max_blocks, stream)
+                                           : erpl_launch_f32(a, c->block, max_blocks, stream);
+  if (rc != 0) return fail(ERPL_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return ERPL_OK;
+}
+
+int erpl_mc_last_stats(erpl_ctx* c, double* total_steps, double* wave_iterations) {
+  if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
+  unsigned long long h[4] = {0, 0, 0, 0};
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+  if (total_steps) *total_steps = (double)h[1];
+  if (wave_iterations) *wave_iterations = (double)h[2];
+  return ERPL_OK;
+}
+
+}  // extern "C"

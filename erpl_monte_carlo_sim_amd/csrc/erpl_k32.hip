@@ -1,0 +1,12 @@
+// fp32 throughput instantiation (BASELINE configs 3-5): algebraic shortcuts + hardware
+// transcendental instructions; time stays fp64.
+#define ERPL_REAL float
+#define ERPL_FAITHFUL 0
+#ifndef ERPL_FAST_F32
+#define ERPL_FAST_F32 1
+#endif
+#define ERPL_SUFFIX f32
+#define ERPL_CAT_(a, b) a##b
+#define ERPL_CAT(a, b) ERPL_CAT_(a, b)
+#define ERPL_LAUNCH_NAME erpl_launch_f32
+#include "erpl_kernels.inc"

@@ -1,0 +1,90 @@
+// erpl_tables.h — device-side constant tables shared by the host API (erpl_api.cpp) and the
+// kernel translation units.  Everything here is derived on the HOST in fp64 from erpl_config
+// with the reference's own expressions (so the values are bit-identical to what the Python
+// reference recomputes on every call), then staged to LDS / scalar registers by the kernels.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/erpl_mc.h"
+
+#define ERPL_MAX_UNION_KNOTS (2 * ERPL_MAX_MACH_KNOTS)
+#define ERPL_MACH_REC 8         // x0a cd0_y0 cd0_s cda_y0 cda_s x0b cp_y0 cp_s
+#define ERPL_COAST_TABLE 2048   // rail-iteration counts covered by the NaN fast-forward table
+
+// Scalar constants, uniform over the batch.  X-macro so the fp64 master copy can be converted to
+// the kernel's working precision field by field.
+#define ERPL_SCALARS(X)                                                                        \
+  X(dq2)            /* (diameter/4)**2                      rocket.py:122 */                    \
+  X(cg_dry)         /* center_of_mass_dry                   rocket.py:31  */                    \
+  X(prop_cg)        /* center_of_mass_dry - 0.5             rocket.py:116 */                    \
+  X(third)          /* propellant_length**2 / 12 = 4/12     rocket.py:123 */                    \
+  X(Ixx_dry) X(Iyy_dry)                                                                          \
+  X(ref_area) X(ref_diam) X(cp_location)                                                         \
+  X(AR)             /* 2 s^2 / fin_area                     rocket.py:177 */                    \
+  X(two_pi_AR)      /* 2*pi*AR                              rocket.py:180 */                    \
+  X(cos_sweep) X(cos_sweep_c) /* cos(sweep), max(cos(sweep),1e-6)  rocket.py:179-180 */         \
+  X(AR_over_cos)    /* AR / cos_sweep_c (fast path only) */                                      \
+  X(stall_angle) X(max_angle) X(inv_stall_span) /* radians(15), radians(45), 1/(max-stall) */    \
+  X(chute_area) X(chute_cd) X(chute_alt) X(power_off)                                            \
+  X(P0) X(T0) X(lapse) X(Rg) X(g0) X(h_tropo) X(h_strat) X(T_strat)                             \
+  X(tropo_exp)      /* g/(R*lapse)                          environment.py:33 */                \
+  X(p11) X(p20) X(p25) /* layer base pressures              environment.py:38-75 */             \
+  X(grad_exp)       /* g/(R*0.0028)                         environment.py:81 */                \
+  X(dt_rail) X(dt_flight) X(half_dt) X(dt_sixth) X(max_time) X(rail_length)                     \
+  X(pitch_damping) X(yaw_damping)
+
+template <typename R>
+struct ErplScalars {
+#define X(name) R name;
+  ERPL_SCALARS(X)
+#undef X
+};
+
+// Master tables in fp64 (device global memory); kernels convert while staging into LDS.
+struct ErplTables {
+  ErplScalars<double> s64;
+  ErplScalars<float> s32;
+  double dt_rail, dt_flight, max_time;  // fp64 copies for the time accumulation
+  int32_t motor_kind, n_curve, n_union, n_coast;
+  double curve_t[ERPL_MAX_CURVE_KNOTS], curve_f[ERPL_MAX_CURVE_KNOTS];
+  double union_knots[ERPL_MAX_UNION_KNOTS];
+  double mach_rec[(ERPL_MAX_UNION_KNOTS + 1) * ERPL_MACH_REC];
+  // NaN fast-forward: a trajectory whose position is all-NaN can no longer trip any event
+  // (every comparison is false), so it runs `while t < max_time: t += dt` to the end.  Its final
+  // time and step count depend only on the number of rail iterations (t is an accumulated sum),
+  // so the host tabulates them once per config.
+  double coast_t[ERPL_COAST_TABLE];
+  int32_t coast_steps[ERPL_COAST_TABLE];
+};
+
+// Arguments of both kernels (passed by value).
+struct ErplKArgs {
+  int64_t n;
+  int32_t k_wind, flags;
+  const double* ic;
+  const double* rocket;
+  const double* motor;
+  const double* alt_grid;
+  const void* wind;
+  double* summary;
+  int32_t* status;
+  // workspace written by the rail kernel, read by the flight kernel
+  void* ws_state;      // [14][n] in working precision
+  double* ws_t;        // [n] rail-exit time
+  int32_t* ws_nrail;   // [n] rail iterations
+  // trajectory capture
+  int64_t n_traj, traj_stride, traj_cap;
+  const int64_t* traj_ids;
+  double* traj;
+  int64_t* traj_len;
+  const ErplTables* tables;
+  unsigned long long* counters;  // [0] queue head, [1] total steps, [2] wave iterations
+  int32_t refill_threshold;
+  int32_t reserved;
+};
+
+// launchers implemented in erpl_k64.hip / erpl_k32.hip
+extern "C++" {
+int erpl_launch_f64(const ErplKArgs& a, int block, int max_blocks, void* stream);
+int erpl_launch_f32(const ErplKArgs& a, int block, int max_blocks, void* stream);
+}

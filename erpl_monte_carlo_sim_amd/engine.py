@@ -1,0 +1,130 @@
+"""TrajectoryEngine — thin Python driver of the C ABI (include/erpl_mc.h).
+
+PyTorch-ROCm is used only as plumbing: it owns the device buffers (SoA tensors) and the HIP
+stream; every number is produced by the hand-written HIP kernels behind `erpl_mc_run_batch`.
+No CPU execution path exists here: if the HIP library or a GPU is missing, construction raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+
+
+class DeviceBatch:
+    """Per-sample SoA tensors resident in HBM (the layout `erpl_batch` points at)."""
+
+    def __init__(self, ic, rocket, motor, alt_grid, wind, precision):
+        self.ic, self.rocket, self.motor = ic, rocket, motor
+        self.alt_grid, self.wind = alt_grid, wind
+        self.precision = precision
+        self.n = int(ic.shape[1])
+        self.k_wind = 0 if wind is None else int(wind.shape[0])
+
+    def input_bytes(self):
+        b = self.ic.numel() * 8 + self.rocket.numel() * 8 + self.motor.numel() * 8
+        if self.wind is not None:
+            b += self.wind.numel() * self.wind.element_size() + self.alt_grid.numel() * 8
+        return b
+
+    @staticmethod
+    def from_host(hb, device, precision=_abi.PREC_F64):
+        """Upload a flatten.HostBatch.  The wind table is stored in the working precision."""
+        if hb.k_wind > _abi.MAX_WIND_KNOTS:
+            raise _abi.ErplError(f"{hb.k_wind} wind knots exceed the ABI limit {_abi.MAX_WIND_KNOTS}")
+        if hb.k_wind and not np.all(np.diff(hb.alt_grid) > 0):
+            raise _abi.ErplError("altitude_profile must be strictly increasing")
+        if hb.k_wind and not (np.all(np.isfinite(hb.wind)) and np.all(np.isfinite(hb.alt_grid))):
+            raise _abi.ErplError("wind profile must be finite")
+        wdt = torch.float64 if precision == _abi.PREC_F64 else torch.float32
+        f64 = dict(dtype=torch.float64, device=device)
+        ic = torch.as_tensor(np.ascontiguousarray(hb.ic), **f64)
+        rocket = torch.as_tensor(np.ascontiguousarray(hb.rocket), **f64)
+        motor = torch.as_tensor(np.ascontiguousarray(hb.motor), **f64)
+        if hb.k_wind:
+            alt = torch.as_tensor(np.ascontiguousarray(hb.alt_grid), **f64)
+            wind = torch.as_tensor(np.ascontiguousarray(hb.wind), device=device).to(wdt).contiguous()
+        else:
+            alt, wind = None, None
+        return DeviceBatch(ic, rocket, motor, alt, wind, precision)
+
+
+class TrajectoryEngine:
+    """One engine (= one `erpl_ctx`) per GPU / torch.distributed rank."""
+
+    def __init__(self, device=None):
+        self.lib = _abi.load_library()
+        if not torch.cuda.is_available():
+            raise _abi.ErplError("no GPU visible to PyTorch-ROCm; this engine has no CPU fallback")
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._ctx = C.c_void_p()
+        _abi.check(self.lib, self.lib.erpl_mc_create(idx, C.byref(self._ctx)), "erpl_mc_create")
+        self._cfg = None
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self.lib.erpl_mc_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_config(self, cfg):
+        _abi.check(self.lib, self.lib.erpl_mc_set_config(self._ctx, C.byref(cfg)), "erpl_mc_set_config")
+        self._cfg = cfg
+
+    def set_launch(self, block_threads=256, max_blocks=0, refill_threshold=8):
+        _abi.check(self.lib, self.lib.erpl_mc_set_launch(self._ctx, block_threads, max_blocks, refill_threshold),
+                   "erpl_mc_set_launch")
+
+    def reserve(self, n):
+        _abi.check(self.lib, self.lib.erpl_mc_reserve(self._ctx, n), "erpl_mc_reserve")
+
+    def alloc_outputs(self, n):
+        summary = torch.empty((_abi.SUMMARY_DIM, n), dtype=torch.float64, device=self.device)
+        status = torch.empty((n,), dtype=torch.int32, device=self.device)
+        return summary, status
+
+    def run(self, db, flags=0, summary=None, status=None, traj_ids=None, traj_stride=1, traj_cap=0,
+            stream=None):
+        """Enqueue rail + flight kernels for the batch on the current torch stream.
+        Returns (summary [16, n] f64, status [n] i32[, traj [m, cap, 15] f64, traj_len [m] i64]);
+        asynchronous with respect to the host."""
+        if summary is None or status is None:
+            summary, status = self.alloc_outputs(db.n)
+        b = _abi.ErplBatch()
+        b.n, b.precision, b.k_wind, b.flags = db.n, db.precision, db.k_wind, flags
+        b.ic, b.rocket, b.motor = db.ic.data_ptr(), db.rocket.data_ptr(), db.motor.data_ptr()
+        b.alt_grid = db.alt_grid.data_ptr() if db.k_wind else None
+        b.wind = db.wind.data_ptr() if db.k_wind else None
+        o = _abi.ErplOut()
+        o.summary, o.status = summary.data_ptr(), status.data_ptr()
+        traj = tlen = ids = None
+        if traj_ids is not None and len(traj_ids):
+            ids = torch.as_tensor(np.asarray(traj_ids, dtype=np.int64), device=self.device)
+            traj = torch.full((len(ids), traj_cap, _abi.TRAJ_DIM), float("nan"), dtype=torch.float64,
+                              device=self.device)
+            tlen = torch.zeros((len(ids),), dtype=torch.int64, device=self.device)
+            o.n_traj, o.traj_ids, o.traj_stride, o.traj_cap = len(ids), ids.data_ptr(), traj_stride, traj_cap
+            o.traj, o.traj_len = traj.data_ptr(), tlen.data_ptr()
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        rc = self.lib.erpl_mc_run_batch(self._ctx, C.byref(b), C.byref(o), C.c_void_p(st.cuda_stream))
+        _abi.check(self.lib, rc, "erpl_mc_run_batch")
+        if traj is not None:
+            self._keep = ids
+            return summary, status, traj, tlen
+        return summary, status
+
+    def last_stats(self):
+        """(physics RK4 steps integrated, wave-iterations) of the last run (synchronises)."""
+        a, b = C.c_double(), C.c_double()
+        torch.cuda.synchronize(self.device)
+        _abi.check(self.lib, self.lib.erpl_mc_last_stats(self._ctx, C.byref(a), C.byref(b)), "erpl_mc_last_stats")
+        return a.value, b.value

@@ -1,0 +1,304 @@
+"""GPU parity tests (run on a real MI355X: `pytest -m gpu`).  Every test drives the HIP kernels
+through the C ABI (erpl_mc_run_batch) and compares with
+  (1) the golden vectors captured from the imported Python reference, and
+  (2) the CPU oracle on the same seeded inputs.
+
+Tolerances (stated per BASELINE north_star: per-sample apogee within 0.1 % of the CPU reference):
+  fp64 kernel, healthy flights : 1e-9 relative on apogee / first-descent apogee / range,
+                                 identical step counts and termination reasons
+  fp64 kernel, diverging flights (error amplification 1e3..1e4): 1e-6 on
+                                 first-descent apogee, match-RATE >= 99 % at 1e-3 on the reference's
+                                 global-argmax apogee
+  fp32 kernel                  : 1e-3 (the north-star 0.1 %) on first-descent apogee of healthy
+                                 flights, match-rate reported for diverging ones
+"""
+import numpy as np
+import pytest
+import torch
+
+from erpl_monte_carlo_sim_amd import _abi, flatten, models
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from erpl_monte_carlo_sim_amd.engine import TrajectoryEngine
+    eng = TrajectoryEngine(torch.device("cuda", 0))
+    yield eng
+    eng.close()
+
+
+def run_gpu(engine, cfg, hb, prec=_abi.PREC_F64, flags=0, **kw):
+    from erpl_monte_carlo_sim_amd.engine import DeviceBatch
+    engine.set_config(cfg)
+    db = DeviceBatch.from_host(hb, engine.device, prec)
+    out = engine.run(db, flags=flags, **kw)
+    torch.cuda.synchronize()
+    return tuple(o.cpu().numpy() for o in out)
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    same = (a == b) | (np.isnan(a) & np.isnan(b))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        e = np.abs(a - b) / np.abs(b)
+    return np.where(same, 0.0, e)
+
+
+def mc_batch(kind, n, base="csv", stream="seed_i", planar=False, start=0):
+    pl = flatten.generate_parameter_samples(H.UNCERTAINTY, start + n, stream=stream)[start:]
+    kw = dict(base_altitude_profile=H.CSV_ALT, base_wind_profile=H.CSV_WIND) if base == "csv" else {}
+    return flatten.dispersed_batch(models.Rocket(), H.make_motor(kind), models.WindModel(), H.EXAMPLE_IC, pl,
+                                   planar=planar, **kw)
+
+
+# ------------------------------------------------------------------ vs golden (the reference itself)
+@pytest.mark.parametrize("name", ["flights_named", "flights_planar", "flights_mc"])
+def test_fp64_vs_reference_golden(engine, oracle, name):
+    idx, arr = H.load_flights(name)
+    for g, entries in H.group_flights(idx).items():
+        cfg = H.make_config(g[0])
+        hb = H.batch_from_golden(entries, arr)
+        summ, status = run_gpu(engine, cfg, hb)
+        osum, ostat = oracle.run_batch(cfg, hb)
+        for i, e in enumerate(entries):
+            s = e["summary"]
+            assert summ[_abi.SUM_RAIL_EXIT_TIME, i] == s["rail_exit_time"]
+            assert relerr(summ[_abi.SUM_RAIL_EXIT_SPEED, i], s["rail_exit_speed"]) < 1e-12
+            healthy = np.isfinite(s["range"]) and s["range"] < 1e5 and s["n_steps"] > 20000
+            tol = 1e-9 if healthy else 1e-6
+            assert relerr(summ[_abi.SUM_FIRST_APOGEE_ALT, i], s["first_apogee"]) < tol, (e["key"],)
+            if healthy:
+                assert int(summ[_abi.SUM_STEPS, i]) == s["n_steps"]
+                assert relerr(summ[_abi.SUM_APOGEE_ALT, i], s["apogee_altitude"]) < 1e-9
+                assert relerr(summ[_abi.SUM_RANGE, i], s["range"]) < 1e-7
+                assert relerr(summ[_abi.SUM_FLIGHT_TIME, i], s["flight_time"]) < 1e-14
+                assert (status[i] & 0xFF) == _abi.END_GROUND and (status[i] & _abi.ST_CHUTE)
+            elif np.isfinite(s["apogee_altitude"]):
+                assert relerr(summ[_abi.SUM_APOGEE_ALT, i], s["apogee_altitude"]) < 1e-5, (e["key"],)
+            else:
+                assert status[i] & _abi.ST_NAN
+        # and the oracle agrees on how every trajectory ended
+        assert np.mean((status & 0xFF) == (ostat & 0xFF)) >= 0.97
+
+
+# ------------------------------------------------------------------ vs oracle, BASELINE config 2
+def test_cfg2_set_r_1k_fp64_match_rate(engine, oracle):
+    """1k reference-faithful dispersed samples (seed=i stream, example config, CSV wind), fp64,
+    full reference termination logic.  Gate: apogee match-rate at 0.1 %."""
+    hb = mc_batch("liquid", 1000)
+    cfg = H.make_config("liquid")
+    summ, status = run_gpu(engine, cfg, hb)
+    osum, ostat = oracle.run_batch(cfg, hb)
+    e_ap = relerr(summ[_abi.SUM_APOGEE_ALT], osum[_abi.SUM_APOGEE_ALT])
+    e_fa = relerr(summ[_abi.SUM_FIRST_APOGEE_ALT], osum[_abi.SUM_FIRST_APOGEE_ALT])
+    rate_ap = np.mean(e_ap <= 1e-3)
+    rate_fa = np.mean(e_fa <= 1e-3)
+    print(f"cfg2 Set R fp64: apogee match {rate_ap:.4f}, first-apogee match {rate_fa:.4f}, "
+          f"median err {np.median(e_ap):.2e}/{np.median(e_fa):.2e}, "
+          f"same end reason {np.mean((status & 0xFF) == (ostat & 0xFF)):.4f}, "
+          f"same step count {np.mean(summ[_abi.SUM_STEPS] == osum[_abi.SUM_STEPS]):.4f}")
+    assert rate_ap >= 0.99 and rate_fa >= 0.99
+    assert np.mean((status & 0xFF) == (ostat & 0xFF)) >= 0.99
+    # rail phase is exact
+    assert np.array_equal(summ[_abi.SUM_RAIL_EXIT_TIME], osum[_abi.SUM_RAIL_EXIT_TIME])
+    assert np.max(relerr(summ[_abi.SUM_RAIL_EXIT_SPEED], osum[_abi.SUM_RAIL_EXIT_SPEED])) < 1e-12
+
+
+def test_cfg2_set_p_to_apogee_fp64(engine, oracle):
+    """Planar healthy dispersions integrated to apogee (BASELINE cfg 2 'to apogee'): 1e-9."""
+    hb = mc_batch("liquid", 256, planar=True)
+    cfg = H.make_config("liquid")
+    summ, status = run_gpu(engine, cfg, hb, flags=_abi.FLAG_STOP_AT_APOGEE)
+    osum, ostat = oracle.run_batch(cfg, hb, flags=_abi.FLAG_STOP_AT_APOGEE)
+    assert np.array_equal(status, ostat)
+    assert np.array_equal(summ[_abi.SUM_STEPS], osum[_abi.SUM_STEPS])
+    for row in (_abi.SUM_FIRST_APOGEE_ALT, _abi.SUM_APOGEE_ALT, _abi.SUM_RANGE, _abi.SUM_MAX_SPEED):
+        assert np.max(relerr(summ[row], osum[row])) < 1e-9, row
+    assert np.array_equal(summ[_abi.SUM_FLIGHT_TIME], osum[_abi.SUM_FLIGHT_TIME])
+    assert np.array_equal(summ[_abi.SUM_FIRST_APOGEE_TIME], osum[_abi.SUM_FIRST_APOGEE_TIME])
+
+
+@pytest.mark.parametrize("kind,base", [("solid", "csv"), ("liquid", "none"), ("solid", "none")])
+def test_motor_and_wind_variants_fp64(engine, oracle, kind, base):
+    """Solid thrust curve, 100-knot synthetic wind."""
+    hb = mc_batch(kind, 128, base=base, planar=True)
+    cfg = H.make_config(kind)
+    summ, status = run_gpu(engine, cfg, hb, flags=_abi.FLAG_STOP_AT_APOGEE)
+    osum, ostat = oracle.run_batch(cfg, hb, flags=_abi.FLAG_STOP_AT_APOGEE)
+    assert np.array_equal(status, ostat)
+    assert np.max(relerr(summ[_abi.SUM_FIRST_APOGEE_ALT], osum[_abi.SUM_FIRST_APOGEE_ALT])) < 1e-9
+    assert np.max(relerr(summ[_abi.SUM_RANGE], osum[_abi.SUM_RANGE])) < 1e-8
+
+
+def test_no_wind_profile_fp64(engine, oracle):
+    hb = mc_batch("liquid", 64, planar=True)
+    hb0 = flatten.HostBatch(hb.n, 0)
+    hb0.ic, hb0.rocket, hb0.motor = hb.ic, hb.rocket, hb.motor
+    cfg = H.make_config("liquid")
+    summ, status = run_gpu(engine, cfg, hb0)
+    osum, ostat = oracle.run_batch(cfg, hb0)
+    assert np.array_equal(status & 0xFF, ostat & 0xFF)
+    assert np.max(relerr(summ[_abi.SUM_APOGEE_ALT], osum[_abi.SUM_APOGEE_ALT])) < 1e-9
+    ok = osum[_abi.SUM_RANGE] < 1e5
+    assert np.max(relerr(summ[_abi.SUM_RANGE], osum[_abi.SUM_RANGE])[ok]) < 1e-7
+
+
+def test_full_flight_with_parachute_fp64(engine, oracle):
+    """cfg 5 ingredient: CSV wind + parachute-deploy event, flights to touchdown."""
+    hb = mc_batch("liquid", 64, planar=True)
+    cfg = H.make_config("liquid")
+    summ, status = run_gpu(engine, cfg, hb)
+    osum, ostat = oracle.run_batch(cfg, hb)
+    assert np.array_equal(status & 0xFF, ostat & 0xFF)
+    landed = ((ostat & 0xFF) == _abi.END_GROUND) & (osum[_abi.SUM_RANGE] < 1e5)
+    assert landed.sum() > 40
+    assert np.all((status[landed] & _abi.ST_CHUTE) != 0)
+    assert np.array_equal(summ[_abi.SUM_STEPS][landed], osum[_abi.SUM_STEPS][landed])
+    assert np.max(relerr(summ[_abi.SUM_RANGE], osum[_abi.SUM_RANGE])[landed]) < 1e-7
+    assert np.max(relerr(summ[_abi.SUM_FINAL_VZ], osum[_abi.SUM_FINAL_VZ])[landed]) < 1e-7
+
+
+def test_nan_trajectories_fast_forward_is_exact(engine, oracle):
+    """Non-finite trajectories run to max_time in the reference.  The kernel
+    fast-forwards them through the host-tabulated time accumulation: steps and flight_time
+    must equal the oracle's brute-force loop exactly."""
+    hb = mc_batch("liquid", 64, stream="seed_42")
+    cfg = H.make_config("liquid")
+    summ, status = run_gpu(engine, cfg, hb)
+    osum, ostat = oracle.run_batch(cfg, hb)
+    nanrun = ((ostat & 0xFF) == _abi.END_MAX_TIME)
+    assert nanrun.sum() >= 3
+    assert np.array_equal((status & 0xFF)[nanrun], (ostat & 0xFF)[nanrun])
+    assert np.array_equal(summ[_abi.SUM_STEPS][nanrun], osum[_abi.SUM_STEPS][nanrun])
+    assert np.array_equal(summ[_abi.SUM_FLIGHT_TIME][nanrun], osum[_abi.SUM_FLIGHT_TIME][nanrun])
+    assert np.all(np.isnan(summ[_abi.SUM_APOGEE_ALT][nanrun]))
+    assert np.all((status[nanrun] & _abi.ST_NAN) != 0)
+    # apogee_time = time of the FIRST NaN altitude (np.argmax semantics)
+    same = np.abs(summ[_abi.SUM_APOGEE_TIME][nanrun] - osum[_abi.SUM_APOGEE_TIME][nanrun]) <= 0.0051
+    assert np.all(same)
+
+
+# ------------------------------------------------------------------ fp32 kernel
+def test_fp32_first_apogee_within_0p1_percent(engine, oracle):
+    hb = mc_batch("liquid", 512, planar=True)
+    cfg = H.make_config("liquid")
+    summ, status = run_gpu(engine, cfg, hb, prec=_abi.PREC_F32, flags=_abi.FLAG_STOP_AT_APOGEE)
+    osum, ostat = oracle.run_batch(cfg, hb, flags=_abi.FLAG_STOP_AT_APOGEE)
+    e = relerr(summ[_abi.SUM_FIRST_APOGEE_ALT], osum[_abi.SUM_FIRST_APOGEE_ALT])
+    print(f"fp32 Set P: first-apogee max rel err {e.max():.2e}, median {np.median(e):.2e}")
+    assert e.max() < 1e-3
+    assert np.max(np.abs(summ[_abi.SUM_STEPS] - osum[_abi.SUM_STEPS])) <= 25  # apogee time within 0.125 s
+    assert np.array_equal(summ[_abi.SUM_RAIL_EXIT_TIME], osum[_abi.SUM_RAIL_EXIT_TIME])
+    assert np.max(relerr(summ[_abi.SUM_RAIL_EXIT_SPEED], osum[_abi.SUM_RAIL_EXIT_SPEED])) < 2e-5
+
+
+def test_fp32_set_r_match_rate(engine, oracle):
+    """Diverging samples: fp32 parity is only meaningful on the first-descent apogee (fact 6)."""
+    hb = mc_batch("liquid", 1000)
+    cfg = H.make_config("liquid")
+    summ, status = run_gpu(engine, cfg, hb, prec=_abi.PREC_F32)
+    osum, ostat = oracle.run_batch(cfg, hb)
+    e_fa = relerr(summ[_abi.SUM_FIRST_APOGEE_ALT], osum[_abi.SUM_FIRST_APOGEE_ALT])
+    e_ap = relerr(summ[_abi.SUM_APOGEE_ALT], osum[_abi.SUM_APOGEE_ALT])
+    print(f"fp32 Set R: first-apogee match-rate@1e-3 {np.mean(e_fa <= 1e-3):.4f}, "
+          f"apogee(argmax) match-rate@1e-3 {np.mean(e_ap <= 1e-3):.4f}")
+    assert np.mean(e_fa <= 1e-3) >= 0.90
+
+
+def test_fp32_full_flight_landing(engine, oracle):
+    hb = mc_batch("liquid", 128, planar=True)
+    cfg = H.make_config("liquid")
+    summ, status = run_gpu(engine, cfg, hb, prec=_abi.PREC_F32)
+    osum, ostat = oracle.run_batch(cfg, hb)
+    landed = ((ostat & 0xFF) == _abi.END_GROUND) & (osum[_abi.SUM_RANGE] < 1e5)
+    agree = (status & 0xFF)[landed] == _abi.END_GROUND
+    # the post-apogee descent tumbles (stall model + destabilising yaw term) and is chaotic: a
+    # few percent of fp32 trajectories leave the fp64 solution there; the rate is
+    # reported, apogee and flight time are asserted on the ones that stay together
+    print(f"fp32 full flight: {agree.mean():.3f} of fp64-landed samples also land in fp32")
+    assert agree.mean() > 0.80
+    sel = np.where(landed)[0][agree]
+    assert np.max(relerr(summ[_abi.SUM_APOGEE_ALT][sel], osum[_abi.SUM_APOGEE_ALT][sel])) < 1e-3
+    assert np.median(relerr(summ[_abi.SUM_FLIGHT_TIME][sel], osum[_abi.SUM_FLIGHT_TIME][sel])) < 1e-3
+
+
+# ------------------------------------------------------------------ structure of the launch
+def test_launch_geometry_does_not_change_results(engine):
+    """Sharding equivalence (SURVEY §4 iv): block size, resident-block cap and refill threshold
+    only change which lane integrates which sample -> bitwise identical summaries."""
+    hb = mc_batch("liquid", 1500)
+    cfg = H.make_config("liquid")
+    base = None
+    try:
+        for block, max_blocks, refill in ((256, 0, 8), (64, 0, 1), (256, 2, 1), (128, 3, 64), (64, 5, 17)):
+            engine.set_launch(block, max_blocks, refill)
+            for prec in (_abi.PREC_F64, _abi.PREC_F32):
+                summ, status = run_gpu(engine, cfg, hb, prec=prec)
+                if base is None:
+                    base = {}
+                if prec not in base:
+                    base[prec] = (summ, status)
+                else:
+                    assert np.array_equal(status, base[prec][1]), (block, max_blocks, refill, prec)
+                    assert np.array_equal(summ, base[prec][0], equal_nan=True), (block, max_blocks, refill, prec)
+    finally:
+        engine.set_launch(256, 0, 8)
+
+
+@pytest.mark.parametrize("n", [1, 63, 65, 257])
+def test_ragged_batch_sizes(engine, oracle, n):
+    hb = mc_batch("liquid", n, planar=True)
+    cfg = H.make_config("liquid")
+    summ, status = run_gpu(engine, cfg, hb, flags=_abi.FLAG_STOP_AT_APOGEE)
+    osum, ostat = oracle.run_batch(cfg, hb, flags=_abi.FLAG_STOP_AT_APOGEE)
+    assert np.array_equal(status, ostat)
+    assert np.max(relerr(summ[_abi.SUM_FIRST_APOGEE_ALT], osum[_abi.SUM_FIRST_APOGEE_ALT])) < 1e-9
+
+
+def test_trajectory_capture(engine, oracle):
+    hb = mc_batch("liquid", 96, planar=True)
+    cfg = H.make_config("liquid")
+    ids = [0, 17, 95]
+    summ, status, traj, tlen = run_gpu(engine, cfg, hb, traj_ids=ids, traj_stride=50, traj_cap=1200)
+    osum, ostat, otraj, otlen = oracle.run_batch(cfg, hb, traj_ids=ids, traj_stride=50, traj_cap=1200)
+    assert np.array_equal(tlen, otlen)
+    for m in range(len(ids)):
+        k = int(tlen[m])
+        healthy = osum[_abi.SUM_RANGE, ids[m]] < 1e5
+        assert np.array_equal(traj[m, :k, 0], otraj[m, :k, 0])  # time stamps are exact
+        if healthy:
+            scale = np.maximum(np.abs(otraj[m, :k, 1:]), 1e-6)
+            assert np.max(np.abs(traj[m, :k, 1:] - otraj[m, :k, 1:]) / scale) < 1e-6
+    # capturing must not change the summaries
+    s2, st2 = run_gpu(engine, cfg, hb)
+    assert np.array_equal(summ, s2, equal_nan=True) and np.array_equal(status, st2)
+
+
+def test_error_paths(engine):
+    import ctypes as C
+    lib = engine.lib
+    ctx = C.c_void_p()
+    assert lib.erpl_mc_create(0, C.byref(ctx)) == 0
+    b, o = _abi.ErplBatch(), _abi.ErplOut()
+    b.n = 4
+    assert lib.erpl_mc_run_batch(ctx, C.byref(b), C.byref(o), None) == -4  # no config yet
+    cfg = H.make_config("liquid")
+    cfg.n_cd = 0
+    assert lib.erpl_mc_set_config(ctx, C.byref(cfg)) == -1
+    cfg = H.make_config("liquid")
+    cfg.cd_mach[1] = float("nan")
+    assert lib.erpl_mc_set_config(ctx, C.byref(cfg)) == -1
+    cfg = H.make_config("liquid")
+    assert lib.erpl_mc_set_config(ctx, C.byref(cfg)) == 0
+    assert lib.erpl_mc_run_batch(ctx, C.byref(b), C.byref(o), None) == -1  # NULL buffers
+    assert b"NULL" in lib.erpl_mc_last_error()
+    b.n = 0
+    assert lib.erpl_mc_run_batch(ctx, C.byref(b), C.byref(o), None) == 0   # empty batch is a no-op
+    assert lib.erpl_mc_set_launch(ctx, 100, 0, 8) == -1
+    assert lib.erpl_mc_create(99, C.byref(C.c_void_p())) == -1
+    assert lib.erpl_mc_destroy(ctx) == 0
