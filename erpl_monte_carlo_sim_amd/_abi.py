@@ -17,6 +17,7 @@ TRAJ_DIM = 15
 MAX_MACH_KNOTS = 16
 MAX_CURVE_KNOTS = 32
 MAX_WIND_KNOTS = 1024
+PROFILE_RING = 256
 
 MOTOR_LIQUID, MOTOR_SOLID = 0, 1
 PREC_F64, PREC_F32 = 0, 1
@@ -83,7 +84,8 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_
 # every symbol include/erpl_mc.h declares
 EXPORTS = ("erpl_mc_abi_version", "erpl_mc_last_error", "erpl_mc_create", "erpl_mc_destroy",
            "erpl_mc_set_config", "erpl_mc_reserve", "erpl_mc_run_batch", "erpl_mc_set_launch",
-           "erpl_mc_last_stats")
+           "erpl_mc_last_stats", "erpl_mc_set_profiling", "erpl_mc_last_kernel_ms",
+           "erpl_mc_kernel_ms_history")
 
 _lib = None
 
@@ -112,6 +114,10 @@ def load_library(path=None):
     lib.erpl_mc_run_batch.argtypes = [C.c_void_p, C.POINTER(ErplBatch), C.POINTER(ErplOut), C.c_void_p]
     lib.erpl_mc_set_launch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.erpl_mc_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.erpl_mc_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    lib.erpl_mc_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.erpl_mc_kernel_ms_history.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                              C.POINTER(C.c_int)]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if a declared symbol is not exported
         if name not in ("erpl_mc_last_error",):

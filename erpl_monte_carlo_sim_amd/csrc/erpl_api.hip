@@ -113,6 +113,12 @@ int build_tables(const erpl_config& c, ErplTables& T) {
   s.dt_sixth = s.dt_flight / 6.0;
   s.max_time = c.max_time; s.rail_length = c.rail_length;
   s.pitch_damping = c.pitch_damping; s.yaw_damping = c.yaw_damping;
+  s.inv_T0 = 1.0 / s.T0; s.inv_Ts = 1.0 / s.T_strat; s.inv_Rg = 1.0 / s.Rg;
+  s.k_iso = -s.g0 / (s.Rg * s.T_strat) * M_LOG2E;
+  s.k_meso = s.g0 * M_LOG2E / s.Rg;
+  s.two_pi_AR_cos = s.two_pi_AR * s.cos_sweep;
+  s.area_diam = s.ref_area * s.ref_diam;
+  s.chute_k = 0.5 * s.chute_cd * s.chute_area;
   convert_scalars(T.s64, T.s32);
   T.dt_rail = s.dt_rail; T.dt_flight = s.dt_flight; T.max_time = s.max_time;
   T.motor_kind = c.motor_kind;
@@ -137,6 +143,21 @@ int build_tables(const erpl_config& c, ErplTables& T) {
     r[3] = y0; r[4] = sl;
     interval_record(c.cp_mach, c.cp_shift, c.n_cp, below, left, x0, y0, sl);
     r[5] = x0; r[6] = y0; r[7] = sl;
+  }
+
+  {  // atmosphere layer records for the fast path (see erpl_tables.h)
+    const double inf = INFINITY;
+    auto rec = [&](int k, double aT, double bT, double Tlo, double Thi, double invTref, double eL,
+                   double href, double eH, double eM, double base) {
+      double* r = &T.atm_rec[k * ERPL_ATM_REC];
+      r[0] = aT; r[1] = bT; r[2] = Tlo; r[3] = Thi; r[4] = invTref; r[5] = eL;
+      r[6] = href; r[7] = eH; r[8] = eM; r[9] = base; r[10] = 0; r[11] = 0;
+    };
+    rec(0, -s.lapse, s.T0, -inf, inf, s.inv_T0, s.tropo_exp, 0.0, 0.0, 0.0, s.P0);
+    rec(1, 0.0, s.T_strat, -inf, inf, s.inv_Ts, 0.0, s.h_tropo, s.k_iso, 0.0, s.p11);
+    rec(2, 0.001, s.T_strat - 0.001 * s.h_strat, -inf, 228.65, s.inv_Ts, 0.0, s.h_strat, s.k_iso, 0.0, s.p20);
+    rec(3, 0.001, s.T_strat - 0.001 * s.h_strat, -inf, 228.65, s.inv_Ts, s.grad_exp, s.h_strat, 0.0, 0.0, s.p25);
+    rec(4, -0.0028, 228.65 + 0.0028 * 32000.0, 180.0, inf, 1.0 / 228.65, 0.0, 32000.0, 0.0, -s.k_meso, 868.02);
   }
 
   // NaN fast-forward table (see erpl_tables.h): final t and step count of
@@ -173,6 +194,7 @@ struct erpl_ctx {
   int device = 0;
   int n_cu = 256;
   bool has_cfg = false;
+  ErplTables h_tables;            // host copy (scalars are passed to the kernels by value)
   ErplTables* d_tables = nullptr;
   void* ws_state = nullptr;
   double* ws_t = nullptr;
@@ -180,6 +202,9 @@ struct erpl_ctx {
   int64_t cap = 0;
   unsigned long long* d_counters = nullptr;
   int block = 256, max_blocks = 0, refill = 8;
+  bool profiling = false;
+  long long profiled_runs = 0;
+  hipEvent_t ev[3 * ERPL_PROFILE_RING] = {};
 };
 
 extern "C" {
@@ -200,7 +225,8 @@ int erpl_mc_create(int device, erpl_ctx** out) {
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
   hipError_t e = hipMalloc((void**)&c->d_tables, sizeof(ErplTables));
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, 4 * sizeof(unsigned long long));
-  if (e != hipSuccess) { delete c; return fail(ERPL_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+  for (int i = 0; i < 3 * ERPL_PROFILE_RING && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
+  if (e != hipSuccess) { delete c; return fail(ERPL_ERR_HIP, "hipMalloc/hipEventCreate: %s", hipGetErrorString(e)); }
   *out = c;
   return ERPL_OK;
 }
@@ -210,13 +236,15 @@ int erpl_mc_destroy(erpl_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_tables); (void)hipFree(c->d_counters);
   (void)hipFree(c->ws_state); (void)hipFree(c->ws_t); (void)hipFree(c->ws_nrail);
+  for (int i = 0; i < 3 * ERPL_PROFILE_RING; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   delete c;
   return ERPL_OK;
 }
 
 int erpl_mc_set_config(erpl_ctx* c, const erpl_config* cfg) {
   if (!c || !cfg) return fail(ERPL_ERR_INVALID, "NULL argument");
-  static thread_local ErplTables T;
+  ErplTables& T = c->h_tables;
+  c->has_cfg = false;
   int rc = build_tables(*cfg, T);
   if (rc != ERPL_OK) return rc;
   HIP_TRY(hipSetDevice(c->device));
@@ -281,11 +309,49 @@ int erpl_mc_run_batch(erpl_ctx* c, const erpl_batch* b, const erpl_out* o, void*
   a.tables = c->d_tables;
   a.counters = c->d_counters;
   a.refill_threshold = c->refill;
+  const ErplTables& T = c->h_tables;
+  a.n_union = T.n_union; a.n_curve = T.n_curve; a.motor_kind = T.motor_kind; a.n_coast = T.n_coast;
+  a.dt_rail = T.dt_rail; a.dt_flight = T.dt_flight; a.max_time = T.max_time;
   const int max_blocks = c->max_blocks > 0 ? c->max_blocks : c->n_cu * 8;
-  int rc = (b->precision == ERPL_PREC_F64) ? erpl_launch_f64(a, c->block, max_blocks, stream)
-                                           : erpl_launch_f32(a, c->block, max_blocks, stream);
+  void** ev = c->profiling ? (void**)&c->ev[3 * (c->profiled_runs % ERPL_PROFILE_RING)] : nullptr;
+  int rc = (b->precision == ERPL_PREC_F64) ? erpl_launch_f64(a, &T.s64, c->block, max_blocks, stream, ev)
+                                           : erpl_launch_f32(a, &T.s32, c->block, max_blocks, stream, ev);
+  if (c->profiling && rc == 0) c->profiled_runs++;
   if (rc != 0) return fail(ERPL_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
   return ERPL_OK;
+}
+
+int erpl_mc_set_profiling(erpl_ctx* c, int enable) {
+  if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
+  c->profiling = enable != 0;
+  c->profiled_runs = 0;
+  return ERPL_OK;
+}
+
+int erpl_mc_kernel_ms_history(erpl_ctx* c, int max, float* rail_ms, float* flight_ms, int* n_out) {
+  if (!c || !n_out || max < 0) return fail(ERPL_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  long long avail = c->profiled_runs < ERPL_PROFILE_RING ? c->profiled_runs : ERPL_PROFILE_RING;
+  long long m = avail < max ? avail : max;
+  for (long long k = 0; k < m; ++k) {
+    const long long run = c->profiled_runs - m + k;
+    hipEvent_t* e = &c->ev[3 * (run % ERPL_PROFILE_RING)];
+    HIP_TRY(hipEventSynchronize(e[2]));
+    float a = 0.f, b = 0.f;
+    HIP_TRY(hipEventElapsedTime(&a, e[0], e[1]));
+    HIP_TRY(hipEventElapsedTime(&b, e[1], e[2]));
+    if (rail_ms) rail_ms[k] = a;
+    if (flight_ms) flight_ms[k] = b;
+  }
+  *n_out = (int)m;
+  return ERPL_OK;
+}
+
+int erpl_mc_last_kernel_ms(erpl_ctx* c, float* rail_ms, float* flight_ms) {
+  if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
+  if (c->profiled_runs <= 0) return fail(ERPL_ERR_INVALID, "no profiled run_batch on this context");
+  int n = 0;
+  return erpl_mc_kernel_ms_history(c, 1, rail_ms, flight_ms, &n);
 }
 
 int erpl_mc_last_stats(erpl_ctx* c, double* total_steps, double* wave_iterations) {

@@ -9,6 +9,8 @@
 
 #define ERPL_MAX_UNION_KNOTS (2 * ERPL_MAX_MACH_KNOTS)
 #define ERPL_MACH_REC 8         // x0a cd0_y0 cd0_s cda_y0 cda_s x0b cp_y0 cp_s
+#define ERPL_ATM_LAYERS 5
+#define ERPL_ATM_REC 12          // aT bT Tlo Thi invTref eL href eH eM base (2 pad)
 #define ERPL_COAST_TABLE 2048   // rail-iteration counts covered by the NaN fast-forward table
 
 // Scalar constants, uniform over the batch.  X-macro so the fp64 master copy can be converted to
@@ -31,7 +33,14 @@
   X(p11) X(p20) X(p25) /* layer base pressures              environment.py:38-75 */             \
   X(grad_exp)       /* g/(R*0.0028)                         environment.py:81 */                \
   X(dt_rail) X(dt_flight) X(half_dt) X(dt_sixth) X(max_time) X(rail_length)                     \
-  X(pitch_damping) X(yaw_damping)
+  X(pitch_damping) X(yaw_damping)                                                                \
+  /* host-folded constants used only by the fast (non-faithful) RHS */                           \
+  X(inv_T0) X(inv_Ts) X(inv_Rg)                                                                  \
+  X(k_iso)          /* -g/(R*T_strat) * log2(e)  : isothermal layers as exp2 */                  \
+  X(k_meso)         /* g*log2(e)/R               : mesosphere scale-height term */               \
+  X(two_pi_AR_cos)  /* 2*pi*AR*cos(sweep) */                                                     \
+  X(area_diam)      /* reference_area * reference_diameter */                                    \
+  X(chute_k)        /* 0.5 * parachute_cd * parachute_area */
 
 template <typename R>
 struct ErplScalars {
@@ -49,6 +58,9 @@ struct ErplTables {
   double curve_t[ERPL_MAX_CURVE_KNOTS], curve_f[ERPL_MAX_CURVE_KNOTS];
   double union_knots[ERPL_MAX_UNION_KNOTS];
   double mach_rec[(ERPL_MAX_UNION_KNOTS + 1) * ERPL_MACH_REC];
+  // Atmosphere layers of environment.py:26-103 as one formula (fast path, LDS-staged):
+  //   T = clamp(bT + aT*h, Tlo, Thi);  P = base * 2^( eL*log2(T*invTref) + (h-href)*(eH + eM/T) )
+  double atm_rec[ERPL_ATM_LAYERS * ERPL_ATM_REC];
   // NaN fast-forward: a trajectory whose position is all-NaN can no longer trip any event
   // (every comparison is false), so it runs `while t < max_time: t += dt` to the end.  Its final
   // time and step count depend only on the number of rail iterations (t is an accumulated sum),
@@ -80,11 +92,17 @@ struct ErplKArgs {
   const ErplTables* tables;
   unsigned long long* counters;  // [0] queue head, [1] total steps, [2] wave iterations
   int32_t refill_threshold;
-  int32_t reserved;
+  int32_t n_union, n_curve, motor_kind, n_coast;   // uniform table sizes (also in *tables)
+  double dt_rail, dt_flight, max_time;             // fp64 time constants
 };
 
 // launchers implemented in erpl_k64.hip / erpl_k32.hip
 extern "C++" {
-int erpl_launch_f64(const ErplKArgs& a, int block, int max_blocks, void* stream);
-int erpl_launch_f32(const ErplKArgs& a, int block, int max_blocks, void* stream);
+// ev: NULL or three hipEvent_t recorded before the rail kernel, between the kernels and after the
+// flight kernel, on `stream`.
+// scalars: host pointer to ErplScalars<double> / ErplScalars<float>, passed to the kernels BY VALUE
+// (kernel-argument segment -> scalar registers; a pointer into global memory would be re-read
+// through the vector memory path on every use because the kernels also store to global memory).
+int erpl_launch_f64(const ErplKArgs& a, const void* scalars, int block, int max_blocks, void* stream, void** ev);
+int erpl_launch_f32(const ErplKArgs& a, const void* scalars, int block, int max_blocks, void* stream, void** ev);
 }

@@ -122,6 +122,25 @@ class TrajectoryEngine:
             return summary, status, traj, tlen
         return summary, status
 
+    def set_profiling(self, enable=True):
+        """Record HIP events around the two kernels on the launch stream (erpl_mc_set_profiling)."""
+        _abi.check(self.lib, self.lib.erpl_mc_set_profiling(self._ctx, int(bool(enable))), "erpl_mc_set_profiling")
+
+    def last_kernel_ms(self):
+        """(rail_ms, flight_ms) device durations of the last profiled run (synchronises on its end)."""
+        a, b = C.c_float(), C.c_float()
+        _abi.check(self.lib, self.lib.erpl_mc_last_kernel_ms(self._ctx, C.byref(a), C.byref(b)),
+                   "erpl_mc_last_kernel_ms")
+        return a.value, b.value
+
+    def kernel_ms_history(self, max_runs=_abi.PROFILE_RING):
+        """Per-launch (rail_ms[], flight_ms[]) of the most recent profiled runs, oldest first."""
+        m = min(int(max_runs), _abi.PROFILE_RING)
+        ra, fa, n = (C.c_float * m)(), (C.c_float * m)(), C.c_int(0)
+        _abi.check(self.lib, self.lib.erpl_mc_kernel_ms_history(self._ctx, m, ra, fa, C.byref(n)),
+                   "erpl_mc_kernel_ms_history")
+        return list(ra[:n.value]), list(fa[:n.value])
+
     def last_stats(self):
         """(physics RK4 steps integrated, wave-iterations) of the last run (synchronises)."""
         a, b = C.c_double(), C.c_double()

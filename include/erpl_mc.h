@@ -184,6 +184,17 @@ int erpl_mc_set_launch(erpl_ctx* ctx, int block_threads, int max_blocks, int ref
  * total RK4 steps integrated over all samples and total wave-iterations executed. */
 int erpl_mc_last_stats(erpl_ctx* ctx, double* total_steps, double* wave_iterations);
 
+/* Kernel timing with HIP events recorded on the SAME stream as the kernels (enable before
+ * run_batch; read after the stream has been synchronised).  rail_ms / flight_ms are the device
+ * durations of the two kernels of the last run_batch. */
+int erpl_mc_set_profiling(erpl_ctx* ctx, int enable);
+int erpl_mc_last_kernel_ms(erpl_ctx* ctx, float* rail_ms, float* flight_ms);
+/* The events live in a ring of ERPL_PROFILE_RING launches, so a timed loop needs no host sync
+ * inside it: afterwards this returns the durations of the last min(max, ring, profiled runs)
+ * launches, oldest first; *n_out = how many were written. */
+#define ERPL_PROFILE_RING 256
+int erpl_mc_kernel_ms_history(erpl_ctx* ctx, int max, float* rail_ms, float* flight_ms, int* n_out);
+
 #ifdef __cplusplus
 }
 #endif
