@@ -129,8 +129,8 @@ def main():
     summary, status = eng.alloc_outputs(n)
     gathered = gathered_st = None
     if world > 1:
-        gathered = torch.empty((world, _abi.SUMMARY_DIM, n), dtype=torch.float64, device=device)
-        gathered_st = torch.empty((world, n), dtype=torch.int32, device=device)
+        gathered = torch.empty((world * _abi.SUMMARY_DIM, n), dtype=torch.float64, device=device)
+        gathered_st = torch.empty((world * n,), dtype=torch.int32, device=device)
 
     def step():
         eng.run(db, flags=flags, summary=summary, status=status)

@@ -1,0 +1,70 @@
+"""Sample sharding over ranks + gather of per-sample summaries.
+
+Samples are independent, so the data path has NO collective: rank r integrates a contiguous block
+of the batch on its own GPU.  The only exchange is the result collection that replaces the
+reference's ProcessPoolExecutor fan-in (monte_carlo.py:76-83): one all-gather of the
+[16, n/world] summary block and the [n/world] status word per rank (RCCL over xGMI when the
+process group is "nccl"; "gloo" in the CPU tests).
+"""
+import numpy as np
+import torch
+
+
+def world():
+    d = torch.distributed
+    if d.is_available() and d.is_initialized():
+        return d.get_rank(), d.get_world_size()
+    return 0, 1
+
+
+def shard_bounds(n, rank, world_size):
+    """Contiguous block [lo, hi) of rank `rank`; every rank's block has ceil(n/world) slots, the
+    last ones possibly empty, so that the gathered tensor is rectangular."""
+    per = -(-n // world_size)
+    lo = min(n, rank * per)
+    hi = min(n, lo + per)
+    return lo, hi, per
+
+
+def all_gather_summaries(summary, status, n_total, group=None):
+    """summary [S, n_local], status [n_local] of this rank -> ([S, n_total], [n_total]) on every
+    rank.  Tensors stay on their device (GPU for nccl/RCCL, CPU for gloo)."""
+    rank, ws = world()
+    if ws == 1:
+        return summary, status
+    d = torch.distributed
+    _, _, per = shard_bounds(n_total, rank, ws)
+    S = summary.shape[0]
+    pad_s = torch.full((S, per), float("nan"), dtype=summary.dtype, device=summary.device)
+    pad_t = torch.zeros((per,), dtype=status.dtype, device=status.device)
+    pad_s[:, : summary.shape[1]] = summary
+    pad_t[: status.shape[0]] = status
+    # outputs are the rank-major concatenation along dim 0 (the layout both RCCL and gloo accept)
+    out_s = torch.empty((ws * S, per), dtype=summary.dtype, device=summary.device)
+    out_t = torch.empty((ws * per,), dtype=status.dtype, device=status.device)
+    d.all_gather_into_tensor(out_s, pad_s.contiguous(), group=group)
+    d.all_gather_into_tensor(out_t, pad_t.contiguous(), group=group)
+    full_s = out_s.view(ws, S, per).permute(1, 0, 2).reshape(S, ws * per)[:, :n_total].contiguous()
+    full_t = out_t.reshape(ws * per)[:n_total].contiguous()
+    return full_s, full_t
+
+
+def run_sharded(host_batch, runner, group=None):
+    """Integrate `host_batch` (all samples, identical on every rank) with this rank's `runner` on
+    its contiguous shard and gather.  runner(HostBatch) -> (summary [S, m] tensor, status [m] tensor).
+    Returns NumPy (summary [S, n], status [n]) identical on every rank."""
+    rank, ws = world()
+    n = host_batch.n
+    lo, hi, _ = shard_bounds(n, rank, ws)
+    if hi > lo:
+        summ, stat = runner(host_batch.take(np.arange(lo, hi)))
+    else:
+        summ = stat = None
+    if ws == 1:
+        return summ.cpu().numpy(), stat.cpu().numpy()
+    if summ is None:  # empty shard (n < world): contribute padding only
+        ref_dev = torch.device("cuda", torch.cuda.current_device()) if torch.distributed.get_backend(group) == "nccl" else torch.device("cpu")
+        summ = torch.empty((16, 0), dtype=torch.float64, device=ref_dev)
+        stat = torch.empty((0,), dtype=torch.int32, device=ref_dev)
+    full_s, full_t = all_gather_summaries(summ, stat, n, group)
+    return full_s.cpu().numpy(), full_t.cpu().numpy()

@@ -1,0 +1,122 @@
+"""CPU tests: outlier filter + statistics against the reference's golden output, and the
+shard/all-gather layer on a world_size-2 gloo group (the GPU engine is replaced by the CPU oracle
+as the per-rank runner: what is under test here is the partitioning and the collective)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from erpl_monte_carlo_sim_amd import _abi, analysis, dist, flatten, models
+
+import helpers as H
+
+
+def test_analyze_matches_reference_stats():
+    g = H.load_json("stats.json")
+    inp = g["inputs"]
+    n = len(inp["apogee_altitude"])
+    params = flatten.generate_parameter_samples(H.UNCERTAINTY, n)
+    results = [{"apogee_altitude": inp["apogee_altitude"][i], "range": inp["range"][i],
+                "flight_time": inp["flight_time"][i], "simulation_id": i, "parameters": params[i]} for i in range(n)]
+    results[inp["none_index"]] = None
+    out = analysis.analyze(results)
+    assert out["n_samples"] == g["n_samples"] and out["n_failed"] == g["n_failed"] and out["n_outliers"] == g["n_outliers"]
+    for key in ("apogee_altitude", "range", "flight_time"):
+        for stat in ("mean", "std", "min", "max"):
+            assert out[key][stat] == pytest.approx(g[key][stat], rel=1e-14), (key, stat)
+        assert np.allclose(out[key]["percentiles"], g[key]["percentiles"], rtol=1e-14)
+    assert [r["simulation_id"] for r in out["results"]] == g["valid_ids"]
+    assert [r["simulation_id"] for r in out["outliers"]] == g["outlier_ids"]
+    assert [r["outlier_reasons"] for r in out["outliers"]] == g["outlier_reasons"]
+    pr, gr = out["parameter_ranges_observed"], g["parameter_ranges_observed"]
+    assert set(pr) == set(gr)
+    for k in gr:
+        assert np.allclose(pr[k]["min"], gr[k]["min"], rtol=0, atol=0) and np.allclose(pr[k]["max"], gr[k]["max"], rtol=0, atol=0)
+
+
+def test_analyze_error_behaviour():
+    with pytest.raises(ValueError, match="No valid simulation results"):
+        analysis.analyze([None, None])
+    bad = [{"apogee_altitude": 9e4, "range": 1.0, "flight_time": 10.0, "parameters": {}}]
+    with pytest.raises(ValueError, match="No physically reasonable"):
+        analysis.analyze(bad)
+
+
+def test_outlier_mask_equals_reason_list():
+    rng = np.random.RandomState(3)
+    a = np.concatenate([rng.normal(25000, 30000, 500), [np.nan, np.inf, 50.0, 100.0, 80000.0, 88073.4]])
+    r = np.abs(np.concatenate([rng.normal(1e5, 1e5, 500), [1.0, 2.0, np.nan, 200000.0, 200000.1, 5.0]]))
+    f = np.concatenate([rng.normal(400, 200, 500), [1.0, np.nan, 600.0, 600.1, 5.0, 5.0]])
+    m = analysis.outlier_mask(a, r, f)
+    for i in range(len(a)):
+        assert bool(m[i]) == bool(analysis.outlier_reasons(a[i], r[i], f[i])), i
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 8, 9, 1000, 131072):
+        for ws in (1, 2, 3, 8):
+            got = []
+            for r in range(ws):
+                lo, hi, per = dist.shard_bounds(n, r, ws)
+                assert 0 <= hi - lo <= per
+                got += list(range(lo, hi))
+            assert got == list(range(n))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    pl = flatten.generate_parameter_samples(H.UNCERTAINTY, n)
+    hb = flatten.dispersed_batch(models.Rocket(), models.LiquidMotor(), models.WindModel(), H.EXAMPLE_IC, pl,
+                                 H.CSV_ALT, H.CSV_WIND)
+    cfg = H.make_config("liquid")
+    calls = []
+
+    def runner(shard):
+        calls.append(shard.n)
+        s, t = orc.run_batch(cfg, shard, threads=1)
+        return torch.from_numpy(s), torch.from_numpy(t)
+
+    summ, status = dist.run_sharded(hb, runner)
+    q.put((rank, calls, summ, status))
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [9, 2])
+def test_two_rank_gloo_shard_and_gather(n):
+    """N > 1 path: each rank integrates only its shard; after the all-gather every rank holds the
+    same [16, n] summaries, equal to the single-process result."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=180) for _ in procs], key=lambda o: o[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    from oracle import oracle as orc
+    pl = flatten.generate_parameter_samples(H.UNCERTAINTY, n)
+    hb = flatten.dispersed_batch(models.Rocket(), models.LiquidMotor(), models.WindModel(), H.EXAMPLE_IC, pl,
+                                 H.CSV_ALT, H.CSV_WIND)
+    ref_s, ref_t = orc.run_batch(H.make_config("liquid"), hb, threads=2)
+    per = -(-n // 2)
+    assert outs[0][1] == [per] and outs[1][1] == [n - per]
+    for rank, calls, summ, status in outs:
+        assert np.array_equal(summ, ref_s, equal_nan=True), rank
+        assert np.array_equal(status, ref_t), rank
