@@ -180,6 +180,12 @@ def main():
         es = 4 if prec == _abi.PREC_F32 else 8
         algo_bytes = (db.input_bytes() + 2 * n * (14 * es + 8 + 4) + n * (_abi.SUMMARY_DIM * 8 + 4))
         hbm_gbps = algo_bytes / ((fl + rl) * 1e-3) / 1e9
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+        # (FETCH_SIZE / WRITE_SIZE need the profiler, they cannot be read from inside this process)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")
+        if os.path.exists(tpath) and args.workload == "set_s" and n == 131072 and args.precision == "f32":
+            traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
         out = {
             "metric": "Monte Carlo trajectories/sec (whole node) + apogee-match rate",
             "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps,
@@ -207,7 +213,7 @@ def main():
                 "bound": "valu", "achieved": achieved_tf, "peak": PEAK_FP32_VECTOR_TFLOPS if prec == _abi.PREC_F32 else PEAK_FP32_VECTOR_TFLOPS / 2,
                 "unit": "TFLOP/s",
                 "frac": achieved_tf / (PEAK_FP32_VECTOR_TFLOPS if prec == _abi.PREC_F32 else PEAK_FP32_VECTOR_TFLOPS / 2),
-                "traffic": None,
+                "traffic": traffic,
                 "kernel": "erpl_flight_" + args.precision,
                 "algorithmic_flops_per_step": FLOPS_PER_STEP, "rk4_steps_per_launch": phys_steps,
                 "note": "non-MFMA vector-ALU bound (SURVEY 8d); peak = fp32 vector (= f32 MFMA) rate",
@@ -221,7 +227,7 @@ def main():
         from oracle import oracle as orc
         cores = host_cores()
         if args.cpu_seconds > 0:
-            m0 = min(n, 64 * cores)
+            m0 = min(n, 256 * cores)
             hb0 = host_slice(db, m0)
             t1 = time.perf_counter()
             orc.run_batch(cfg, hb0, flags=flags, threads=cores)
