@@ -227,16 +227,16 @@ def main():
         from oracle import oracle as orc
         cores = host_cores()
         if args.cpu_seconds > 0:
-            m0 = min(n, 256 * cores)
-            hb0 = host_slice(db, m0)
-            t1 = time.perf_counter()
-            orc.run_batch(cfg, hb0, flags=flags, threads=cores)
-            pilot = time.perf_counter() - t1
-            m = int(min(n, max(m0, m0 * args.cpu_seconds / max(pilot, 1e-3))))
-            hb = host_slice(db, m)
-            t1 = time.perf_counter()
-            osum, ostat = orc.run_batch(cfg, hb, flags=flags, threads=cores)
-            cpu_t = time.perf_counter() - t1
+            m = min(n, 256 * cores)
+            cpu_t, osum, ostat = 0.0, None, None
+            for _attempt in range(3):  # grow the sample until it is a 10-30 s measurement
+                hb = host_slice(db, m)
+                t1 = time.perf_counter()
+                osum, ostat = orc.run_batch(cfg, hb, flags=flags, threads=cores)
+                cpu_t = time.perf_counter() - t1
+                if cpu_t >= 0.6 * args.cpu_seconds or m >= n:
+                    break
+                m = int(min(n, max(m + 1, m * args.cpu_seconds / max(cpu_t, 1e-3))))
             out["cpu_baseline"] = {
                 "value": m / cpu_t, "unit": "trajectories/s", "cores": cores, "kind": "port",
                 "sample": f"first {m} samples of rank 0's shard, CPU oracle (C fp64, OpenMP, {cores} threads), {cpu_t:.1f} s",

@@ -224,7 +224,7 @@ int erpl_mc_create(int device, erpl_ctx** out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
   hipError_t e = hipMalloc((void**)&c->d_tables, sizeof(ErplTables));
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, 4 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, 16 * sizeof(unsigned long long));
   for (int i = 0; i < 3 * ERPL_PROFILE_RING && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
   if (e != hipSuccess) { delete c; return fail(ERPL_ERR_HIP, "hipMalloc/hipEventCreate: %s", hipGetErrorString(e)); }
   *out = c;
@@ -297,7 +297,7 @@ int erpl_mc_run_batch(erpl_ctx* c, const erpl_batch* b, const erpl_out* o, void*
     if (rc != ERPL_OK) return rc;
   }
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), st));
+  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), st));
   ErplKArgs a;
   memset(&a, 0, sizeof(a));
   a.n = b->n; a.k_wind = b->k_wind; a.flags = b->flags;
@@ -352,6 +352,15 @@ int erpl_mc_last_kernel_ms(erpl_ctx* c, float* rail_ms, float* flight_ms) {
   if (c->profiled_runs <= 0) return fail(ERPL_ERR_INVALID, "no profiled run_batch on this context");
   int n = 0;
   return erpl_mc_kernel_ms_history(c, 1, rail_ms, flight_ms, &n);
+}
+
+int erpl_mc_debug_counters(erpl_ctx* c, double* out16) {
+  if (!c || !out16) return fail(ERPL_ERR_INVALID, "NULL argument");
+  unsigned long long h[16];
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 16; ++i) out16[i] = (double)h[i];
+  return ERPL_OK;
 }
 
 int erpl_mc_last_stats(erpl_ctx* c, double* total_steps, double* wave_iterations) {

@@ -141,6 +141,12 @@ class TrajectoryEngine:
                    "erpl_mc_kernel_ms_history")
         return list(ra[:n.value]), list(fa[:n.value])
 
+    def debug_counters(self):
+        out = (C.c_double * 16)()
+        torch.cuda.synchronize(self.device)
+        _abi.check(self.lib, self.lib.erpl_mc_debug_counters(self._ctx, out), "erpl_mc_debug_counters")
+        return list(out)
+
     def last_stats(self):
         """(physics RK4 steps integrated, wave-iterations) of the last run (synchronises)."""
         a, b = C.c_double(), C.c_double()

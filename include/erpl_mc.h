@@ -184,6 +184,10 @@ int erpl_mc_set_launch(erpl_ctx* ctx, int block_threads, int max_blocks, int ref
  * total RK4 steps integrated over all samples and total wave-iterations executed. */
 int erpl_mc_last_stats(erpl_ctx* ctx, double* total_steps, double* wave_iterations);
 
+/* Raw device counters of the last run_batch (16 doubles): [0] queue head, [1] RK4 steps, [2] wave
+ * iterations, [8..15] per-segment s_memtime sums of a -DERPL_STAMPS=1 diagnostic build (0 otherwise). */
+int erpl_mc_debug_counters(erpl_ctx* ctx, double* out16);
+
 /* Kernel timing with HIP events recorded on the SAME stream as the kernels (enable before
  * run_batch; read after the stream has been synchronised).  rail_ms / flight_ms are the device
  * durations of the two kernels of the last run_batch. */

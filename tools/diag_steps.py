@@ -43,3 +43,13 @@ for thr in (3000, 5000, 10000, 20000, 40000):
 w = np.nan_to_num(ps, nan=0).reshape(-1, 64)
 print("  per-wave max steps: mean", w.max(1).mean(), "median", np.median(w.max(1)), " per-wave mean steps", w.mean(1).mean())
 print("  end reasons:", {k: int(np.sum((st & 0xFF) == v)) for k, v in (("max_time", 0), ("ground", 1), ("alt", 2), ("coast", 3), ("apogee", 4))})
+
+dc = eng.debug_counters()
+if sum(dc[8:16]) > 0:
+    names = ["refill/ballots", "rhs: wind lookup", "rhs: atm+attitude+mass+thrust", "rhs: chute+aero", "rhs: forces+derivs",
+             "stage combine", "final combine+normalise", "events+finish"]
+    tot = sum(dc[8:16])
+    print("  stamp shares (cycles per wave-step):")
+    for nme, v in zip(names, dc[8:16]):
+        print(f"    {nme:34s} {v / wi:9.1f}  {100 * v / tot:5.1f} %")
+    print(f"    {'total':34s} {tot / wi:9.1f}")
