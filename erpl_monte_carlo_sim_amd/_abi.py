@@ -14,6 +14,7 @@ ROCKET_DIM = 2
 MOTOR_DIM = 4
 SUMMARY_DIM = 16
 TRAJ_DIM = 15
+DIAG_DIM = 17
 MAX_MACH_KNOTS = 16
 MAX_CURVE_KNOTS = 32
 MAX_WIND_KNOTS = 1024
@@ -85,7 +86,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_
 EXPORTS = ("erpl_mc_abi_version", "erpl_mc_last_error", "erpl_mc_create", "erpl_mc_destroy",
            "erpl_mc_set_config", "erpl_mc_reserve", "erpl_mc_run_batch", "erpl_mc_set_launch",
            "erpl_mc_last_stats", "erpl_mc_set_profiling", "erpl_mc_last_kernel_ms",
-           "erpl_mc_kernel_ms_history", "erpl_mc_debug_counters")
+           "erpl_mc_kernel_ms_history", "erpl_mc_debug_counters", "erpl_mc_extract_histories")
 
 _lib = None
 
@@ -119,6 +120,8 @@ def load_library(path=None):
     lib.erpl_mc_kernel_ms_history.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                               C.POINTER(C.c_int)]
     lib.erpl_mc_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.erpl_mc_extract_histories.argtypes = [C.c_void_p, C.POINTER(ErplBatch), C.c_int64, C.c_void_p, C.c_int64,
+                                              C.c_double, C.c_void_p, C.c_void_p]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if a declared symbol is not exported
         if name not in ("erpl_mc_last_error",):

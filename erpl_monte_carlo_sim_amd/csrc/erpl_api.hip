@@ -354,6 +354,30 @@ int erpl_mc_last_kernel_ms(erpl_ctx* c, float* rail_ms, float* flight_ms) {
   return erpl_mc_kernel_ms_history(c, 1, rail_ms, flight_ms, &n);
 }
 
+int erpl_mc_extract_histories(erpl_ctx* c, const erpl_batch* b, int64_t sample, const double* traj, int64_t m,
+                              double time_offset, double* out, void* stream) {
+  if (!c || !b || !traj || !out) return fail(ERPL_ERR_INVALID, "NULL argument");
+  if (!c->has_cfg) return fail(ERPL_ERR_CONFIG, "erpl_mc_set_config has not been called");
+  if (b->precision != ERPL_PREC_F64) return fail(ERPL_ERR_INVALID, "history extraction needs an ERPL_PREC_F64 batch");
+  if (sample < 0 || sample >= b->n || m < 0) return fail(ERPL_ERR_INVALID, "sample/m out of range");
+  if (b->k_wind < 0 || b->k_wind > ERPL_MAX_WIND_KNOTS || (b->k_wind > 0 && (!b->alt_grid || !b->wind)))
+    return fail(ERPL_ERR_INVALID, "bad wind arguments");
+  if (m == 0) return ERPL_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  const ErplTables& T = c->h_tables;
+  ErplKArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n = b->n; a.k_wind = b->k_wind; a.flags = b->flags;
+  a.ic = b->ic; a.rocket = b->rocket; a.motor = b->motor; a.alt_grid = b->alt_grid; a.wind = b->wind;
+  a.summary = out; a.traj = const_cast<double*>(traj); a.traj_cap = m; a.n_traj = sample;
+  a.tables = c->d_tables; a.counters = c->d_counters;
+  a.n_union = T.n_union; a.n_curve = T.n_curve; a.motor_kind = T.motor_kind; a.n_coast = T.n_coast;
+  a.dt_rail = T.dt_rail; a.dt_flight = T.dt_flight; a.max_time = T.max_time;
+  int rc = erpl_launch_extract_f64(a, &T.s64, time_offset, stream);
+  if (rc != 0) return fail(ERPL_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return ERPL_OK;
+}
+
 int erpl_mc_debug_counters(erpl_ctx* c, double* out16) {
   if (!c || !out16) return fail(ERPL_ERR_INVALID, "NULL argument");
   unsigned long long h[16];

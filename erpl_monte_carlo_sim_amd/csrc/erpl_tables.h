@@ -105,4 +105,7 @@ extern "C++" {
 // through the vector memory path on every use because the kernels also store to global memory).
 int erpl_launch_f64(const ErplKArgs& a, const void* scalars, int block, int max_blocks, void* stream, void** ev);
 int erpl_launch_f32(const ErplKArgs& a, const void* scalars, int block, int max_blocks, void* stream, void** ev);
+// extraction of the per-step diagnostic histories (fp64 only): a.traj = records, a.traj_cap = m,
+// a.n_traj = sample index, a.summary = out [m][ERPL_DIAG_DIM]
+int erpl_launch_extract_f64(const ErplKArgs& a, const void* scalars, double time_offset, void* stream);
 }

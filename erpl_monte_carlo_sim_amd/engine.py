@@ -122,6 +122,24 @@ class TrajectoryEngine:
             return summary, status, traj, tlen
         return summary, status
 
+    def extract_histories(self, db, sample, traj, time_offset, stream=None):
+        """Per-step diagnostic histories (simulator.py:496-552) of the records `traj` [m, 15] (device
+        tensor, as produced by run(..., traj_ids=...)) of sample `sample`: returns [m, 17] f64."""
+        traj = traj.contiguous()
+        m = int(traj.shape[0])
+        out = torch.empty((m, _abi.DIAG_DIM), dtype=torch.float64, device=self.device)
+        b = _abi.ErplBatch()
+        b.n, b.precision, b.k_wind, b.flags = db.n, db.precision, db.k_wind, 0
+        b.ic, b.rocket, b.motor = db.ic.data_ptr(), db.rocket.data_ptr(), db.motor.data_ptr()
+        b.alt_grid = db.alt_grid.data_ptr() if db.k_wind else None
+        b.wind = db.wind.data_ptr() if db.k_wind else None
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        rc = self.lib.erpl_mc_extract_histories(self._ctx, C.byref(b), int(sample), C.c_void_p(traj.data_ptr()), m,
+                                                float(time_offset), C.c_void_p(out.data_ptr()),
+                                                C.c_void_p(st.cuda_stream))
+        _abi.check(self.lib, rc, "erpl_mc_extract_histories")
+        return out
+
     def set_profiling(self, enable=True):
         """Record HIP events around the two kernels on the launch stream (erpl_mc_set_profiling)."""
         _abi.check(self.lib, self.lib.erpl_mc_set_profiling(self._ctx, int(bool(enable))), "erpl_mc_set_profiling")

@@ -3,9 +3,10 @@
 Same constructor, same mutable attributes, same `simulate_flight(initial_conditions,
 wind_profile=None, altitude_profile=None) -> dict` with the reference's result keys for the state
 histories, scalar results and rail-exit diagnostics.  One flight = a batch of one sample through
-`erpl_mc_run_batch` in fp64 with full-resolution trajectory capture; nothing is integrated on the
-CPU.  The per-step derived diagnostics of `_extract_results` (mass/thrust/drag/coefficient
-histories, simulator.py:496-552) are the "next" row §8f-1 of SURVEY.md and are not produced yet.
+`erpl_mc_run_batch` in fp64 with full-resolution trajectory capture, followed by
+`erpl_mc_extract_histories` for the per-step derived diagnostics of `_extract_results`
+(mass/thrust/drag/coefficient/stability histories, simulator.py:496-552); nothing is integrated or
+evaluated on the CPU.
 """
 import math
 
@@ -85,6 +86,8 @@ class FlightSimulator:
         torch.cuda.synchronize(eng.device)
         s = summ[:, 0].cpu().numpy()
         n = int(tlen[0].item())
+        # per-step diagnostic histories (_extract_results loop, simulator.py:511-552), on the GPU
+        diag = eng.extract_histories(db, 0, traj[0, :n], float(s[_abi.SUM_RAIL_EXIT_TIME])).cpu().numpy().T
         tr = traj[0, :n].cpu().numpy()            # [n, 15]: absolute time + 14 state
         st = int(status[0].item())
         self.wind_profile, self.altitude_profile = wind_profile, altitude_profile
@@ -97,6 +100,10 @@ class FlightSimulator:
             "position": positions, "velocity": velocities, "quaternion": states[6:10],
             "angular_velocity": states[10:13], "propellant_fraction": states[13],
             "altitude": positions[2], "speed": np.linalg.norm(velocities, axis=0),
+            "euler_angles": diag[0:3], "center_of_mass": diag[3], "mass": diag[4],
+            "moments_of_inertia": diag[5:8], "thrust": diag[8], "drag": diag[9],
+            "cd": diag[10], "cl": diag[11], "cm": diag[12], "cp_location_dynamic": diag[13],
+            "stability_margin": diag[14], "angle_of_attack": diag[15], "sideslip_angle": diag[16],
             "cp_location": self.rocket.cp_location,
             "thrust_curve_time": getattr(self.motor, "thrust_curve_time", None),
             "thrust_curve_thrust": getattr(self.motor, "thrust_curve_thrust", None),

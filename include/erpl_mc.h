@@ -184,6 +184,16 @@ int erpl_mc_set_launch(erpl_ctx* ctx, int block_threads, int max_blocks, int ref
  * total RK4 steps integrated over all samples and total wave-iterations executed. */
 int erpl_mc_last_stats(erpl_ctx* ctx, double* total_steps, double* wave_iterations);
 
+/* Per-step diagnostic histories of FlightSimulator._extract_results (simulator.py:496-552) for m
+ * stored records traj[m][ERPL_TRAJ_DIM] (as written by erpl_out.traj) of sample `sample` of an
+ * ERPL_PREC_F64 batch: out[m][ERPL_DIAG_DIM] = euler(3), center_of_mass, mass, Ixx, Iyy, Izz, thrust,
+ * drag, cd, cl, cm, cp_location_dynamic, stability_margin, angle_of_attack, sideslip_angle.
+ * time_offset is the rail-exit time (the reference evaluates the thrust history at the shifted
+ * time, simulator.py:543).  Device pointers, asynchronous on the stream. */
+#define ERPL_DIAG_DIM 17
+int erpl_mc_extract_histories(erpl_ctx* ctx, const erpl_batch* batch, int64_t sample, const double* traj,
+                              int64_t m, double time_offset, double* out, void* hip_stream);
+
 /* Raw device counters of the last run_batch (16 doubles): [0] queue head, [1] RK4 steps, [2] wave
  * iterations, [8..15] per-segment s_memtime sums of a -DERPL_STAMPS=1 diagnostic build (0 otherwise). */
 int erpl_mc_debug_counters(erpl_ctx* ctx, double* out16);

@@ -569,6 +569,57 @@ int erpl_oracle_wind(const erpl_batch* b, double altitude, double w[3]) {
   return ERPL_OK;
 }
 
+/* Per-step diagnostic histories of FlightSimulator._extract_results (simulator.py:496-552) for the
+ * m stored records traj[m][15] = {absolute time, 14 state} of sample 0 of the batch.
+ * out[m][17] = euler(3), center_of_mass, mass, Ixx, Iyy, Izz, thrust, drag, cd, cl, cm,
+ *              cp_location_dynamic, stability_margin, angle_of_attack, sideslip_angle.
+ * Quirk kept: the thrust history is evaluated at the rail-shifted time (simulator.py:543). */
+int erpl_oracle_extract(const erpl_config* c, const erpl_batch* b, int64_t m, const double* traj,
+                        double time_offset, double* out) {
+  sample s;
+  double ic[ERPL_IC_DIM];
+  load_sample(c, b, 0, &s, ic);
+  for (int64_t r = 0; r < m; ++r) {
+    const double* rec = traj + r * ERPL_TRAJ_DIM;
+    const double time_shifted = rec[0] - time_offset;
+    const double* st = rec + 1;
+    double* o = out + r * 17;
+    /* quaternion_to_euler on the stored quaternion (utils.py:139-144 via :46-70) */
+    double w = st[6], x = st[7], y = st[8], z = st[9];
+    double sinr_cosp = 2 * (w * x + y * z), cosr_cosp = 1 - 2 * (x * x + y * y);
+    o[0] = atan2(sinr_cosp, cosr_cosp);
+    double sinp = 2 * (w * y - z * x);
+    o[1] = (fabs(sinp) >= 1) ? copysign(M_PI / 2, sinp) : asin(sinp);
+    double siny_cosp = 2 * (w * z + x * y), cosy_cosp = 1 - 2 * (y * y + z * z);
+    o[2] = atan2(siny_cosp, cosy_cosp);
+    double mp[5];
+    erpl_oracle_mass_props(c, s.dry_mass, s.propellant_mass, st[13], mp);
+    o[3] = mp[1]; o[4] = mp[0]; o[5] = mp[2]; o[6] = mp[3]; o[7] = mp[4];
+    double atm[4];
+    erpl_oracle_atmosphere(c, st[2], atm);
+    double wind[3];
+    wind_at(&s, st[2], wind);
+    double vrel[3] = {st[3] - wind[0], st[4] - wind[1], st[5] - wind[2]};
+    double R[9];
+    quaternion_to_rotation_matrix(st + 6, R);
+    double vb[3];
+    for (int i = 0; i < 3; ++i) vb[i] = (R[i] * vrel[0] + R[3 + i] * vrel[1]) + R[6 + i] * vrel[2];
+    double mach = mach_number(vrel, atm[0]);
+    double aoa = angle_of_attack(vb), beta = sideslip_angle(vb);
+    double cp_val = c->cp_location + erpl_oracle_interp(mach, c->cp_mach, c->cp_shift, c->n_cp);
+    double co[7];
+    erpl_oracle_aero(c, mach, aoa, beta, mp[1], st[13] > 0, co);
+    double q_dyn = 0.5 * atm[2] * sq(norm3(vrel));
+    o[8] = motor_thrust(&s, time_shifted, atm[1]);
+    o[9] = q_dyn * co[0] * c->reference_area;
+    o[10] = co[0]; o[11] = co[1]; o[12] = co[3];
+    o[13] = cp_val;
+    o[14] = (cp_val - mp[1]) / c->reference_diameter;
+    o[15] = aoa; o[16] = beta;
+  }
+  return ERPL_OK;
+}
+
 /* motor KATs: out = {thrust, mass_flow, propellant_remaining} for sample 0 */
 int erpl_oracle_motor(const erpl_config* c, const erpl_batch* b, double t, double pressure, double out[3]) {
   sample s;

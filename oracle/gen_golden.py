@@ -104,7 +104,7 @@ def _capturing_simulate(self, initial_conditions, wind_profile=None, altitude_pr
 ref_sim.FlightSimulator.simulate_flight = _capturing_simulate
 
 
-def summarize(res, decim):
+def summarize(res, decim, diag=False):
     """Scalar summary + decimated history of one reference result dict."""
     t = np.asarray(res["time"])  # shifted by rail time
     pos = np.asarray(res["position"])
@@ -153,6 +153,14 @@ def summarize(res, decim):
         "hist_time_abs": (t[idx] + float(res["rail_exit_time"])),
         "hist_state": states[:, idx].copy(),
     }
+    if diag:
+        # per-step diagnostic histories of _extract_results (simulator.py:496-552), same decimation
+        rows = [res["euler_angles"][0], res["euler_angles"][1], res["euler_angles"][2], res["center_of_mass"],
+                res["mass"], res["moments_of_inertia"][0], res["moments_of_inertia"][1],
+                res["moments_of_inertia"][2], res["thrust"], res["drag"], res["cd"], res["cl"], res["cm"],
+                res["cp_location_dynamic"], res["stability_margin"], res["angle_of_attack"],
+                res["sideslip_angle"]]
+        out["hist_diag"] = np.vstack([np.asarray(r, dtype=np.float64)[idx] for r in rows])
     return out
 
 
@@ -187,7 +195,7 @@ def job_named(spec):
                                   ref_env.StandardAtmosphere(), ref_env.WindModel())
     with quiet():
         res = sim.simulate_flight(dict(EXAMPLE_IC), w, alt)
-    return name, res["_captured"], summarize(res, 100)
+    return name, res["_captured"], summarize(res, 100, diag=True)
 
 
 def make_analyzer(kind, base):
@@ -473,7 +481,7 @@ def main():
         with open(os.path.join(OUT, "stats.json"), "w") as fh:
             json.dump(gen_stats(), fh, indent=1)
         print("kat/params/stats done", time.time() - t0, flush=True)
-    if args.only and "flights" not in args.only:
+    if args.only and "flights" not in args.only and "named" not in args.only:
         return
     from multiprocessing import Pool
     named = [("liquid_nowind", "liquid", "none"), ("liquid_planar_csv", "liquid", "planar"),
@@ -485,6 +493,11 @@ def main():
           + [("solid", "csv", "seed_i", i) for i in range(8)]
           + [("solid", "none", "seed_i", i) for i in range(8)])
     planar = [("liquid", i) for i in range(8)] + [("solid", i) for i in range(4)]
+    if args.only == "named":
+        with Pool(args.jobs) as pool:
+            pack_flights(pool.map(job_named, named, chunksize=1), os.path.join(OUT, "flights_named"))
+        print("named done", time.time() - t0, flush=True)
+        return
     with Pool(args.jobs) as pool:
         r_pl = pool.map_async(job_planar, planar, chunksize=1)
         r_nm = pool.map_async(job_named, named, chunksize=1)

@@ -42,6 +42,8 @@ def lib():
         L.erpl_oracle_wind.argtypes = [C.POINTER(_abi.ErplBatch), C.c_double, dp]
         L.erpl_oracle_motor.argtypes = [C.POINTER(_abi.ErplConfig), C.POINTER(_abi.ErplBatch), C.c_double,
                                         C.c_double, dp]
+        L.erpl_oracle_extract.argtypes = [C.POINTER(_abi.ErplConfig), C.POINTER(_abi.ErplBatch), C.c_int64, dp,
+                                          C.c_double, dp]
         _lib = L
     return _lib
 
@@ -143,4 +145,13 @@ def motor(cfg, hb, t, p):
     b = host_batch_struct(hb)
     out = np.zeros(3)
     lib().erpl_oracle_motor(C.byref(cfg), C.byref(b), t, p, _dp(out))
+    return out
+
+
+def extract(cfg, hb, traj, time_offset):
+    """Diagnostic histories (simulator.py:496-552) for the records traj [m, 15] of sample 0."""
+    b = host_batch_struct(hb)
+    tr = np.ascontiguousarray(traj, dtype=np.float64)
+    out = np.zeros((tr.shape[0], 17))
+    lib().erpl_oracle_extract(C.byref(cfg), C.byref(b), tr.shape[0], _dp(tr), float(time_offset), _dp(out))
     return out

@@ -33,6 +33,9 @@ def test_simulate_flight_matches_reference(key, kind, wind):
             w[:, 1] = 0.0
     res = sim.simulate_flight(dict(H.EXAMPLE_IC), w, alt)
     for k in ("time", "position", "velocity", "quaternion", "angular_velocity", "propellant_fraction", "altitude",
+              "mass", "moments_of_inertia", "euler_angles", "center_of_mass", "thrust", "drag", "cd", "cl", "cm",
+              "cp_location_dynamic", "stability_margin", "angle_of_attack", "sideslip_angle",
+              "thrust_curve_time", "thrust_curve_thrust",
               "speed", "apogee_time", "apogee_altitude", "range", "flight_time", "cp_location", "rail_exit_time",
               "rail_exit_position", "rail_exit_velocity", "rail_exit_speed", "rail_exit_euler",
               "rail_exit_angle_of_attack", "rail_exit_sideslip", "wind_at_exit", "initial_conditions",
@@ -64,6 +67,17 @@ def test_simulate_flight_matches_reference(key, kind, wind):
         scale = np.maximum(np.abs(hs), 1e-6)
         assert np.max(np.abs(got - hs) / scale) < 1e-6
     assert np.allclose(res["altitude"], res["position"][2])
+    # per-step diagnostic histories (_extract_results) against the reference's
+    gd = arr[e["tag"] + "_hist_diag"]
+    got_d = np.vstack([res["euler_angles"], res["center_of_mass"][None], res["mass"][None], res["moments_of_inertia"],
+                       res["thrust"][None], res["drag"][None], res["cd"][None], res["cl"][None], res["cm"][None],
+                       res["cp_location_dynamic"][None], res["stability_margin"][None],
+                       res["angle_of_attack"][None], res["sideslip_angle"][None]])[:, hi]
+    assert res["mass"].shape == (n,) and res["moments_of_inertia"].shape == (3, n) and res["euler_angles"].shape == (3, n)
+    if healthy:
+        for r in range(17):
+            scale = np.maximum(np.abs(gd[r]), 1e-6 * max(1.0, np.max(np.abs(gd[r]))))
+            assert np.max(np.abs(got_d[r] - gd[r]) / scale) < 1e-5, r
 
 
 def test_run_monte_carlo_example_config():

@@ -303,3 +303,23 @@ def test_error_paths(engine):
     assert lib.erpl_mc_set_launch(ctx, 100, 0, 8) == -1
     assert lib.erpl_mc_create(99, C.byref(C.c_void_p())) == -1
     assert lib.erpl_mc_destroy(ctx) == 0
+
+
+def test_extract_histories_vs_oracle(engine, oracle):
+    """erpl_mc_extract_histories on GPU-integrated records == oracle evaluation of the same records."""
+    from erpl_monte_carlo_sim_amd.engine import DeviceBatch
+    for kind in ("liquid", "solid"):
+        hb = mc_batch(kind, 8, planar=(kind == "liquid"))
+        cfg = H.make_config(kind)
+        engine.set_config(cfg)
+        db = DeviceBatch.from_host(hb, engine.device, _abi.PREC_F64)
+        summ, status, traj, tlen = engine.run(db, traj_ids=[3], traj_stride=37, traj_cap=2000)
+        torch.cuda.synchronize()
+        k = int(tlen[0].item())
+        t_rail = float(summ[_abi.SUM_RAIL_EXIT_TIME, 3].item())
+        got = engine.extract_histories(db, 3, traj[0, :k], t_rail).cpu().numpy()
+        exp = oracle.extract(cfg, hb.take([3]), traj[0, :k].cpu().numpy(), t_rail)
+        assert np.array_equal(np.isfinite(got), np.isfinite(exp))
+        fin = np.isfinite(exp)
+        scale = np.maximum(np.abs(exp), 1e-9 * np.nanmax(np.abs(np.where(fin, exp, 0)), axis=0, keepdims=True) + 1e-300)
+        assert np.max((np.abs(got - exp) / scale)[fin]) < 1e-9, kind

@@ -234,3 +234,30 @@ def test_stop_at_apogee_flag(oracle):
     assert (status[0] & 0xFF) == _abi.END_APOGEE
     assert int(summ[_abi.SUM_STEPS, 0]) == e["summary"]["first_descent_step"]
     assert close(summ[_abi.SUM_FIRST_APOGEE_ALT, 0], e["summary"]["first_apogee"], 1e-9)
+
+
+DIAG_NAMES = ["euler_roll", "euler_pitch", "euler_yaw", "center_of_mass", "mass", "Ixx", "Iyy", "Izz", "thrust",
+              "drag", "cd", "cl", "cm", "cp_location_dynamic", "stability_margin", "angle_of_attack", "sideslip_angle"]
+
+
+def test_extract_histories_against_reference(oracle):
+    """Per-step diagnostics of _extract_results (simulator.py:496-552) evaluated by the oracle on the
+    REFERENCE's own stored states == the reference's histories (all five named flights, incl. the
+    diverging ones: this is a pointwise function of the state, no chaos involved)."""
+    idx, arr = H.load_flights("flights_named")
+    for e in idx:
+        cfg = H.make_config(e["inputs"]["motor_kind"])
+        hb = H.batch_from_golden([e], arr)
+        hs = arr[e["tag"] + "_hist_state"]            # (14, m) reference states
+        ht = arr[e["tag"] + "_hist_time_abs"]
+        gd = arr[e["tag"] + "_hist_diag"]             # (17, m) reference diagnostics
+        traj = np.vstack([ht[None, :], hs]).T
+        got = oracle.extract(cfg, hb, traj, e["summary"]["rail_exit_time"]).T
+        fin = np.isfinite(gd) & np.isfinite(got)
+        assert np.array_equal(np.isfinite(gd), np.isfinite(got)), e["key"]
+        for r, name in enumerate(DIAG_NAMES):
+            # values that are zero up to rounding noise (angle of attack 1e-18 rad in a no-wind vertical
+            # flight) are compared on an absolute floor
+            scale = np.maximum(np.abs(gd[r]), 1e-6 * max(1.0, np.nanmax(np.abs(gd[r][fin[r]])) if fin[r].any() else 1.0))
+            err = np.abs(got[r] - gd[r])[fin[r]] / scale[fin[r]]
+            assert err.size == 0 or err.max() < 5e-10, (e["key"], name, err.max())
