@@ -106,3 +106,47 @@ def analyze(results, verbose=False):
         "outliers": outliers,
         "parameter_ranges_observed": parameter_ranges(r.get("parameters", {}) for r in valid),
     }
+
+
+def device_statistics(summary, status=None):
+    """Outlier filter + statistics on the gathered [16, n] summary tensor WITHOUT leaving the device
+    (SURVEY.md §8f-3): the same bounds as `outlier_mask` and the same statistics as `calc_stats`
+    (NumPy-style linear-interpolated percentiles, population std) with torch ops, for the 100 k - 10 M
+    sample runs where a Python list of result dicts is not an option.  Works on CPU tensors too."""
+    import torch
+    from . import _abi
+    s = summary.to(torch.float64)
+    apo, rng, ft = s[_abi.SUM_APOGEE_ALT], s[_abi.SUM_RANGE], s[_abi.SUM_FLIGHT_TIME]
+    bad = ~torch.isfinite(apo) | ~torch.isfinite(rng) | ~torch.isfinite(ft)
+    bad |= (apo > MAX_REASONABLE_APOGEE) | (apo < MIN_REASONABLE_APOGEE)
+    bad |= rng > MAX_REASONABLE_RANGE
+    bad |= ft > MAX_REASONABLE_FLIGHT_TIME
+    bad |= apo > _THEORETICAL_MAX_ALTITUDE * 1.2
+    ok = ~bad
+    n_valid = int(ok.sum().item())
+    if n_valid == 0:
+        raise ValueError("No physically reasonable simulation results after outlier filtering")
+    q = torch.tensor([0.05, 0.25, 0.5, 0.75, 0.95], dtype=torch.float64, device=s.device)
+
+    def stats(v):
+        v = v[ok]
+        # torch.quantile is limited to 16 M elements; sort-based linear interpolation has no limit
+        vs, _ = torch.sort(v)
+        pos = q * (vs.numel() - 1)
+        lo = pos.floor().long()
+        hi = torch.clamp(lo + 1, max=vs.numel() - 1)
+        frac = pos - lo.to(torch.float64)
+        pct = vs[lo] + (vs[hi] - vs[lo]) * frac
+        return {"mean": float(v.mean().item()), "std": float(v.std(unbiased=False).item()),
+                "min": float(vs[0].item()), "max": float(vs[-1].item()), "percentiles": pct.tolist()}
+
+    out = {"n_samples": n_valid, "n_failed": 0, "n_outliers": int(bad.sum().item()),
+           "apogee_altitude": stats(apo), "range": stats(rng), "flight_time": stats(ft),
+           "valid_mask": ok}
+    if status is not None:
+        st = status.to(torch.int64) & 0xFF
+        out["termination_counts"] = {name: int((st == code).sum().item()) for code, name in
+                                     enumerate(("max_time", "ground_impact", "excessive_altitude",
+                                                "coast_timeout", "apogee"))}
+        out["n_non_finite"] = int(((status.to(torch.int64) & _abi.ST_NAN) != 0).sum().item())
+    return out

@@ -135,6 +135,34 @@ class MonteCarloAnalyzer:
                                   "cores_used": self.n_cores, "gpus_used": ws}
         return out
 
+    def run_monte_carlo_device(self, initial_conditions, n_samples, seed=1234, precision="f32", planar=False):
+        """Throughput form for 100 k - 10 M samples (BASELINE configs 3-5): dispersions are drawn on the
+        device (`sampling.synthetic_dispersions`, same distributions, torch generator), each rank
+        integrates `n_samples / world` of them, summaries are all-gathered and the outlier filter +
+        statistics run on the device (`analysis.device_statistics`).  Returns the statistics part of
+        the analysis dict plus the gathered tensors; no per-sample dicts."""
+        from . import sampling
+        eng = shared_engine(self.device)
+        eng.set_config(self._config())
+        rank, ws = dist.world()
+        lo, hi, _ = dist.shard_bounds(n_samples, rank, ws)
+        prec = _abi.PREC_F32 if precision == "f32" else _abi.PREC_F64
+        t0 = time.time()
+        db = sampling.synthetic_dispersions(max(hi - lo, 1), self.rocket, self.motor, self.wind_model,
+                                            initial_conditions, eng.device, precision=prec, seed=seed + rank,
+                                            uncertainty=self.uncertainty_params,
+                                            base_altitude_profile=self.base_altitude_profile,
+                                            base_wind_profile=self.base_wind_profile, planar=planar)
+        summ, status = eng.run(db)
+        summ, status = summ[:, : hi - lo], status[: hi - lo]
+        summ, status = dist.all_gather_summaries(summ, status, n_samples)
+        out = analysis.device_statistics(summ, status)
+        torch.cuda.synchronize(eng.device)
+        el = time.time() - t0
+        out["summary"], out["status"] = summ, status
+        out["performance"] = {"total_time": el, "simulations_per_second": n_samples / el, "gpus_used": ws}
+        return out
+
     def run_optimized_monte_carlo(self, initial_conditions, n_samples=1000, chunk_size=None):
         return self.run_monte_carlo(initial_conditions, n_samples, optimized=True)
 

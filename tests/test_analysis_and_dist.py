@@ -55,6 +55,31 @@ def test_outlier_mask_equals_reason_list():
         assert bool(m[i]) == bool(analysis.outlier_reasons(a[i], r[i], f[i])), i
 
 
+def test_device_statistics_equal_host_statistics():
+    """torch implementation (runs on the GPU in production) == the NumPy/reference-pinned one."""
+    rng = np.random.RandomState(11)
+    n = 5000
+    summ = np.zeros((16, n))
+    summ[_abi.SUM_APOGEE_ALT] = rng.normal(25000, 20000, n)
+    summ[_abi.SUM_RANGE] = np.abs(rng.normal(50000, 90000, n))
+    summ[_abi.SUM_FLIGHT_TIME] = rng.normal(300, 150, n)
+    summ[_abi.SUM_APOGEE_ALT, :7] = [np.nan, np.inf, 50.0, 100.0, 80000.0, 88073.4, -np.inf]
+    summ[_abi.SUM_RANGE, 7:10] = [np.nan, 200000.0, 200000.1]
+    status = rng.randint(0, 4, n).astype(np.int32)
+    res = [{"apogee_altitude": summ[0, i], "range": summ[4, i], "flight_time": summ[5, i], "parameters": {}}
+           for i in range(n)]
+    ref = analysis.analyze(res)
+    got = analysis.device_statistics(torch.from_numpy(summ), torch.from_numpy(status))
+    assert got["n_samples"] == ref["n_samples"] and got["n_outliers"] == ref["n_outliers"]
+    for key in ("apogee_altitude", "range", "flight_time"):
+        for stat in ("mean", "std", "min", "max"):
+            assert got[key][stat] == pytest.approx(ref[key][stat], rel=1e-12), (key, stat)
+        assert np.allclose(got[key]["percentiles"], ref[key]["percentiles"], rtol=1e-12)
+    assert sum(got["termination_counts"].values()) == n
+    with pytest.raises(ValueError):
+        analysis.device_statistics(torch.full((16, 4), float("nan"), dtype=torch.float64))
+
+
 def test_shard_bounds_cover_everything():
     for n in (0, 1, 7, 8, 9, 1000, 131072):
         for ws in (1, 2, 3, 8):

@@ -128,3 +128,14 @@ def test_run_monte_carlo_fp32_and_synthetic_wind():
     except ValueError:
         n = 64
     assert n == 64
+
+
+def test_run_monte_carlo_device_large_n():
+    """Throughput form (cfg 3-5): on-device dispersions + integration + on-device statistics."""
+    mc = E.MonteCarloAnalyzer(E.Rocket(), E.LiquidMotor(), E.StandardAtmosphere(), E.WindModel(), verbose=False)
+    out = mc.run_monte_carlo_device(dict(H.EXAMPLE_IC), 20000, planar=True)
+    assert out["n_samples"] + out["n_outliers"] == 20000
+    assert out["n_samples"] > 15000                      # planar dispersions are mostly healthy
+    assert 20000 < out["apogee_altitude"]["mean"] < 32000
+    assert out["summary"].shape == (16, 20000) and out["status"].shape == (20000,)
+    assert sum(out["termination_counts"].values()) == 20000
