@@ -104,12 +104,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)   # one rank per GPU on the driver's 8-GPU node
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        # "nccl" is RCCL on ROCm.  ERPL_BENCH_BACKEND=gloo exists only to rehearse the N > 1 code path on
+        # a box with a single GPU (RCCL refuses two ranks on one device); it is never used for numbers.
+        backend = os.environ.get("ERPL_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     rocket, atm, wm = models.Rocket(), models.StandardAtmosphere(), models.WindModel()
     motor = models.SolidMotor() if args.motor == "solid" else models.LiquidMotor()
@@ -132,11 +140,22 @@ def main():
         gathered = torch.empty((world * _abi.SUMMARY_DIM, n), dtype=torch.float64, device=device)
         gathered_st = torch.empty((world * n,), dtype=torch.int32, device=device)
 
+    gloo_rehearsal = world > 1 and os.environ.get("ERPL_BENCH_BACKEND", "nccl") != "nccl"
+
     def step():
         eng.run(db, flags=flags, summary=summary, status=status)
         if world > 1:  # RCCL all-gather of the per-sample summaries over xGMI (monte_carlo.py:76-83)
-            dist.all_gather_into_tensor(gathered, summary)
-            dist.all_gather_into_tensor(gathered_st, status)
+            if gloo_rehearsal:
+                torch.cuda.synchronize()
+                hs, ht = summary.cpu(), status.cpu()
+                gs = torch.empty((world * _abi.SUMMARY_DIM, n), dtype=torch.float64)
+                gt = torch.empty((world * n,), dtype=torch.int32)
+                dist.all_gather_into_tensor(gs, hs)
+                dist.all_gather_into_tensor(gt, ht)
+                gathered.copy_(gs); gathered_st.copy_(gt)
+            else:
+                dist.all_gather_into_tensor(gathered, summary)
+                dist.all_gather_into_tensor(gathered_st, status)
 
     eng.set_profiling(True)
     for _ in range(args.warmup):
@@ -154,7 +173,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo_rehearsal else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -164,7 +183,7 @@ def main():
     sm = summary.cpu().numpy()
     steps_col = sm[_abi.SUM_STEPS]
     if world > 1:
-        tot = torch.tensor([phys_steps], dtype=torch.float64, device=device)
+        tot = torch.tensor([phys_steps], dtype=torch.float64, device="cpu" if gloo_rehearsal else device)
         dist.all_reduce(tot)
         phys_total = float(tot.item())
     else:
