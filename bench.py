@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--block", type=int, default=256)
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--refill", type=int, default=8)
+    ap.add_argument("--chunk", type=int, default=-1, help="steps per launch between compactions (-1 = library default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,6 +127,8 @@ def main():
     eng = TrajectoryEngine(device)
     eng.set_config(cfg)
     eng.set_launch(args.block, args.max_blocks, args.refill)
+    if args.chunk >= 0:
+        eng.set_chunk(args.chunk)
     n = args.samples_per_gpu
     planar = args.workload.startswith("set_p")
     flags = _abi.FLAG_STOP_AT_APOGEE if args.workload == "set_p_apogee" else 0

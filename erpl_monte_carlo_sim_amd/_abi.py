@@ -86,7 +86,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_
 EXPORTS = ("erpl_mc_abi_version", "erpl_mc_last_error", "erpl_mc_create", "erpl_mc_destroy",
            "erpl_mc_set_config", "erpl_mc_reserve", "erpl_mc_run_batch", "erpl_mc_set_launch",
            "erpl_mc_last_stats", "erpl_mc_set_profiling", "erpl_mc_last_kernel_ms",
-           "erpl_mc_kernel_ms_history", "erpl_mc_debug_counters", "erpl_mc_extract_histories")
+           "erpl_mc_kernel_ms_history", "erpl_mc_debug_counters", "erpl_mc_extract_histories", "erpl_mc_set_chunk")
 
 _lib = None
 
@@ -114,6 +114,7 @@ def load_library(path=None):
     lib.erpl_mc_reserve.argtypes = [C.c_void_p, C.c_int64]
     lib.erpl_mc_run_batch.argtypes = [C.c_void_p, C.POINTER(ErplBatch), C.POINTER(ErplOut), C.c_void_p]
     lib.erpl_mc_set_launch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.erpl_mc_set_chunk.argtypes = [C.c_void_p, C.c_int]
     lib.erpl_mc_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.erpl_mc_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.erpl_mc_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]

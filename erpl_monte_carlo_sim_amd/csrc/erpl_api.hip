@@ -196,9 +196,11 @@ struct erpl_ctx {
   bool has_cfg = false;
   ErplTables h_tables;            // host copy (scalars are passed to the kernels by value)
   ErplTables* d_tables = nullptr;
-  void* ws_state = nullptr;
-  double* ws_t = nullptr;
-  int32_t* ws_nrail = nullptr;
+  void* res_r[2] = {nullptr, nullptr};      // resume-queue records (see erpl_tables.h)
+  double* res_d[2] = {nullptr, nullptr};
+  int32_t* res_i[2] = {nullptr, nullptr};
+  unsigned long long* d_queue = nullptr;    // qcnt[ERPL_MAX_PHASES + 2] followed by qhead[...]
+  int chunk = 0;
   int64_t cap = 0;
   unsigned long long* d_counters = nullptr;
   int block = 256, max_blocks = 0, refill = 8;
@@ -225,6 +227,7 @@ int erpl_mc_create(int device, erpl_ctx** out) {
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
   hipError_t e = hipMalloc((void**)&c->d_tables, sizeof(ErplTables));
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, 16 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_queue, 2 * (ERPL_MAX_PHASES + 2) * sizeof(unsigned long long));
   for (int i = 0; i < 3 * ERPL_PROFILE_RING && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
   if (e != hipSuccess) { delete c; return fail(ERPL_ERR_HIP, "hipMalloc/hipEventCreate: %s", hipGetErrorString(e)); }
   *out = c;
@@ -234,8 +237,8 @@ int erpl_mc_create(int device, erpl_ctx** out) {
 int erpl_mc_destroy(erpl_ctx* c) {
   if (!c) return ERPL_OK;
   (void)hipSetDevice(c->device);
-  (void)hipFree(c->d_tables); (void)hipFree(c->d_counters);
-  (void)hipFree(c->ws_state); (void)hipFree(c->ws_t); (void)hipFree(c->ws_nrail);
+  (void)hipFree(c->d_tables); (void)hipFree(c->d_counters); (void)hipFree(c->d_queue);
+  for (int k = 0; k < 2; ++k) { (void)hipFree(c->res_r[k]); (void)hipFree(c->res_d[k]); (void)hipFree(c->res_i[k]); }
   for (int i = 0; i < 3 * ERPL_PROFILE_RING; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   delete c;
   return ERPL_OK;
@@ -257,12 +260,23 @@ int erpl_mc_reserve(erpl_ctx* c, int64_t n) {
   if (!c || n < 0) return fail(ERPL_ERR_INVALID, "bad argument");
   if (n <= c->cap) return ERPL_OK;
   HIP_TRY(hipSetDevice(c->device));
-  (void)hipFree(c->ws_state); (void)hipFree(c->ws_t); (void)hipFree(c->ws_nrail);
-  c->ws_state = nullptr; c->ws_t = nullptr; c->ws_nrail = nullptr; c->cap = 0;
-  HIP_TRY(hipMalloc(&c->ws_state, (size_t)n * ERPL_STATE_DIM * sizeof(double)));
-  HIP_TRY(hipMalloc((void**)&c->ws_t, (size_t)n * sizeof(double)));
-  HIP_TRY(hipMalloc((void**)&c->ws_nrail, (size_t)n * sizeof(int32_t)));
+  for (int k = 0; k < 2; ++k) {
+    (void)hipFree(c->res_r[k]); (void)hipFree(c->res_d[k]); (void)hipFree(c->res_i[k]);
+    c->res_r[k] = nullptr; c->res_d[k] = nullptr; c->res_i[k] = nullptr;
+  }
+  c->cap = 0;
+  for (int k = 0; k < 2; ++k) {
+    HIP_TRY(hipMalloc(&c->res_r[k], (size_t)n * ERPL_RES_R * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->res_d[k], (size_t)n * ERPL_RES_D * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->res_i[k], (size_t)n * ERPL_RES_I * sizeof(int32_t)));
+  }
   c->cap = n;
+  return ERPL_OK;
+}
+
+int erpl_mc_set_chunk(erpl_ctx* c, int chunk_steps) {
+  if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
+  c->chunk = chunk_steps < 0 ? 0 : chunk_steps;
   return ERPL_OK;
 }
 
@@ -303,7 +317,10 @@ int erpl_mc_run_batch(erpl_ctx* c, const erpl_batch* b, const erpl_out* o, void*
   a.n = b->n; a.k_wind = b->k_wind; a.flags = b->flags;
   a.ic = b->ic; a.rocket = b->rocket; a.motor = b->motor; a.alt_grid = b->alt_grid; a.wind = b->wind;
   a.summary = o->summary; a.status = o->status;
-  a.ws_state = c->ws_state; a.ws_t = c->ws_t; a.ws_nrail = c->ws_nrail;
+  for (int k = 0; k < 2; ++k) { a.res_r[k] = c->res_r[k]; a.res_d[k] = c->res_d[k]; a.res_i[k] = c->res_i[k]; }
+  a.res_cap = c->cap;
+  a.qcnt = c->d_queue; a.qhead = c->d_queue + (ERPL_MAX_PHASES + 2);
+  HIP_TRY(hipMemsetAsync(c->d_queue, 0, 2 * (ERPL_MAX_PHASES + 2) * sizeof(unsigned long long), st));
   a.n_traj = o->n_traj; a.traj_stride = o->traj_stride; a.traj_cap = o->traj_cap;
   a.traj_ids = o->traj_ids; a.traj = o->traj; a.traj_len = o->traj_len;
   a.tables = c->d_tables;
@@ -313,9 +330,20 @@ int erpl_mc_run_batch(erpl_ctx* c, const erpl_batch* b, const erpl_out* o, void*
   a.n_union = T.n_union; a.n_curve = T.n_curve; a.motor_kind = T.motor_kind; a.n_coast = T.n_coast;
   a.dt_rail = T.dt_rail; a.dt_flight = T.dt_flight; a.max_time = T.max_time;
   const int max_blocks = c->max_blocks > 0 ? c->max_blocks : c->n_cu * 8;
+  // step-chunked launches with compaction in between (erpl_mc_set_chunk); every lane ends within
+  // ceil(max_time / dt) + 1 steps, so that many steps' worth of chunks drains the queue
+  int n_phases = 1;
+  a.chunk_steps = 0;
+  if (c->chunk > 0 && T.max_time > 0) {
+    const double max_steps = ceil(T.max_time / T.dt_flight) + 2.0;
+    double chunk = (double)c->chunk;
+    if (ceil(max_steps / chunk) + 1.0 > (double)ERPL_MAX_PHASES) chunk = ceil(max_steps / (double)(ERPL_MAX_PHASES - 2));
+    a.chunk_steps = (int)chunk;
+    n_phases = (int)ceil(max_steps / chunk) + 1;
+  }
   void** ev = c->profiling ? (void**)&c->ev[3 * (c->profiled_runs % ERPL_PROFILE_RING)] : nullptr;
-  int rc = (b->precision == ERPL_PREC_F64) ? erpl_launch_f64(a, &T.s64, c->block, max_blocks, stream, ev)
-                                           : erpl_launch_f32(a, &T.s32, c->block, max_blocks, stream, ev);
+  int rc = (b->precision == ERPL_PREC_F64) ? erpl_launch_f64(a, &T.s64, c->block, max_blocks, n_phases, stream, ev)
+                                           : erpl_launch_f32(a, &T.s32, c->block, max_blocks, n_phases, stream, ev);
   if (c->profiling && rc == 0) c->profiled_runs++;
   if (rc != 0) return fail(ERPL_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
   return ERPL_OK;

@@ -11,6 +11,10 @@
 #define ERPL_MACH_REC 8         // x0a cd0_y0 cd0_s cda_y0 cda_s x0b cp_y0 cp_s
 #define ERPL_ATM_LAYERS 5
 #define ERPL_ATM_REC 12          // aT bT Tlo Thi invTref eL href eH eM base (2 pad)
+#define ERPL_RES_R 20
+#define ERPL_RES_D 5
+#define ERPL_RES_I 5
+#define ERPL_MAX_PHASES 2048
 #define ERPL_COAST_TABLE 2048   // rail-iteration counts covered by the NaN fast-forward table
 
 // Scalar constants, uniform over the batch.  X-macro so the fp64 master copy can be converted to
@@ -80,10 +84,17 @@ struct ErplKArgs {
   const void* wind;
   double* summary;
   int32_t* status;
-  // workspace written by the rail kernel, read by the flight kernel
-  void* ws_state;      // [14][n] in working precision
-  double* ws_t;        // [n] rail-exit time
-  int32_t* ws_nrail;   // [n] rail iterations
+  // Resume queue (ping-pong): lane records written by the rail kernel (phase 0) and by every flight
+  // launch for the lanes that reached their step-chunk limit; the next launch pops them densely.
+  void* res_r[2];              // [ERPL_RES_R][res_cap] working precision: y[14], apogee, first_apogee,
+                               //   max_speed2, max_coast, cx, cy
+  double* res_d[2];            // [ERPL_RES_D][res_cap]: t, t_rail, apogee_t, first_apogee_t, latch_t
+  int32_t* res_i[2];           // [ERPL_RES_I][res_cap]: id, steps, nrail, mode|flags, traj_len
+  int64_t res_cap;
+  unsigned long long* qcnt;    // [ERPL_MAX_PHASES + 2] records available to phase p (phase 0: n)
+  unsigned long long* qhead;   // [ERPL_MAX_PHASES + 2] pop cursor of phase p
+  int32_t phase;               // index of this flight launch
+  int32_t chunk_steps;         // RK4 steps a lane may take per launch (<= 0: unlimited, one launch)
   // trajectory capture
   int64_t n_traj, traj_stride, traj_cap;
   const int64_t* traj_ids;
@@ -103,8 +114,9 @@ extern "C++" {
 // scalars: host pointer to ErplScalars<double> / ErplScalars<float>, passed to the kernels BY VALUE
 // (kernel-argument segment -> scalar registers; a pointer into global memory would be re-read
 // through the vector memory path on every use because the kernels also store to global memory).
-int erpl_launch_f64(const ErplKArgs& a, const void* scalars, int block, int max_blocks, void* stream, void** ev);
-int erpl_launch_f32(const ErplKArgs& a, const void* scalars, int block, int max_blocks, void* stream, void** ev);
+// n_phases flight launches follow the rail launch (1 when a.chunk_steps <= 0).
+int erpl_launch_f64(const ErplKArgs& a, const void* scalars, int block, int max_blocks, int n_phases, void* stream, void** ev);
+int erpl_launch_f32(const ErplKArgs& a, const void* scalars, int block, int max_blocks, int n_phases, void* stream, void** ev);
 // extraction of the per-step diagnostic histories (fp64 only): a.traj = records, a.traj_cap = m,
 // a.n_traj = sample index, a.summary = out [m][ERPL_DIAG_DIM]
 int erpl_launch_extract_f64(const ErplKArgs& a, const void* scalars, double time_offset, void* stream);

@@ -84,6 +84,10 @@ class TrajectoryEngine:
         _abi.check(self.lib, self.lib.erpl_mc_set_launch(self._ctx, block_threads, max_blocks, refill_threshold),
                    "erpl_mc_set_launch")
 
+    def set_chunk(self, chunk_steps):
+        """Step-chunked launches with per-GPU compaction in between (0 = single launch)."""
+        _abi.check(self.lib, self.lib.erpl_mc_set_chunk(self._ctx, int(chunk_steps)), "erpl_mc_set_chunk")
+
     def reserve(self, n):
         _abi.check(self.lib, self.lib.erpl_mc_reserve(self._ctx, n), "erpl_mc_reserve")
 

@@ -180,6 +180,12 @@ int erpl_mc_run_batch(erpl_ctx* ctx, const erpl_batch* batch, const erpl_out* ou
  * persistent flight kernel (0 = library default), lane-refill threshold. */
 int erpl_mc_set_launch(erpl_ctx* ctx, int block_threads, int max_blocks, int refill_threshold);
 
+/* Per-GPU compaction (BASELINE config 5): integrate in launches of `chunk_steps` RK4 steps; lanes
+ * that are still flying at the end of a chunk park their state densely in a resume queue and the
+ * next launch continues them with fully populated waves.  0 = one launch, no compaction.  Results
+ * do not depend on the value (bitwise). */
+int erpl_mc_set_chunk(erpl_ctx* ctx, int chunk_steps);
+
 /* Diagnostics of the last run_batch on this ctx (after the stream has been synchronised):
  * total RK4 steps integrated over all samples and total wave-iterations executed. */
 int erpl_mc_last_stats(erpl_ctx* ctx, double* total_steps, double* wave_iterations);

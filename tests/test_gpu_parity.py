@@ -236,8 +236,11 @@ def test_launch_geometry_does_not_change_results(engine):
     cfg = H.make_config("liquid")
     base = None
     try:
-        for block, max_blocks, refill in ((256, 0, 8), (64, 0, 1), (256, 2, 1), (128, 3, 64), (64, 5, 17)):
+        for block, max_blocks, refill, chunk in ((256, 0, 8, 0), (64, 0, 1, 0), (256, 2, 1, 0), (128, 3, 64, 0),
+                                                 (64, 5, 17, 0), (256, 0, 8, 256), (256, 0, 8, 100), (64, 3, 5, 977),
+                                                 (128, 0, 64, 31)):
             engine.set_launch(block, max_blocks, refill)
+            engine.set_chunk(chunk)
             for prec in (_abi.PREC_F64, _abi.PREC_F32):
                 summ, status = run_gpu(engine, cfg, hb, prec=prec)
                 if base is None:
@@ -245,10 +248,11 @@ def test_launch_geometry_does_not_change_results(engine):
                 if prec not in base:
                     base[prec] = (summ, status)
                 else:
-                    assert np.array_equal(status, base[prec][1]), (block, max_blocks, refill, prec)
-                    assert np.array_equal(summ, base[prec][0], equal_nan=True), (block, max_blocks, refill, prec)
+                    assert np.array_equal(status, base[prec][1]), (block, max_blocks, refill, chunk, prec)
+                    assert np.array_equal(summ, base[prec][0], equal_nan=True), (block, max_blocks, refill, chunk, prec)
     finally:
         engine.set_launch(256, 0, 8)
+        engine.set_chunk(0)
 
 
 @pytest.mark.parametrize("n", [1, 63, 65, 257])
@@ -323,3 +327,19 @@ def test_extract_histories_vs_oracle(engine, oracle):
         fin = np.isfinite(exp)
         scale = np.maximum(np.abs(exp), 1e-9 * np.nanmax(np.abs(np.where(fin, exp, 0)), axis=0, keepdims=True) + 1e-300)
         assert np.max((np.abs(got - exp) / scale)[fin]) < 1e-9, kind
+
+
+def test_chunked_compaction_with_trajectory_capture(engine, oracle):
+    """Step-chunked launches + resume queue must also carry the trajectory-capture state."""
+    hb = mc_batch("liquid", 40, planar=True)
+    cfg = H.make_config("liquid")
+    ids = [1, 39]
+    try:
+        engine.set_chunk(0)
+        ref = run_gpu(engine, cfg, hb, traj_ids=ids, traj_stride=50, traj_cap=1200)
+        engine.set_chunk(300)
+        got = run_gpu(engine, cfg, hb, traj_ids=ids, traj_stride=50, traj_cap=1200)
+    finally:
+        engine.set_chunk(0)
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b, equal_nan=True)

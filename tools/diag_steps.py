@@ -13,6 +13,7 @@ ap.add_argument("--precision", default="f32")
 ap.add_argument("--planar", action="store_true")
 ap.add_argument("--apogee", action="store_true")
 ap.add_argument("--wind", default="syn", choices=["syn", "csv", "none"])
+ap.add_argument("--chunk", type=int, default=0)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 rocket, motor, atm, wm = models.Rocket(), models.LiquidMotor(), models.StandardAtmosphere(), models.WindModel()
@@ -23,6 +24,7 @@ db = sampling.synthetic_dispersions(a.n, rocket, motor, wm, B.EXAMPLE_IC, dev, p
 if a.wind == "none":
     db.wind = None; db.alt_grid = None; db.k_wind = 0
 eng.set_profiling(True)
+eng.set_chunk(a.chunk)
 flags = _abi.FLAG_STOP_AT_APOGEE if a.apogee else 0
 for _ in range(2):
     s, st = eng.run(db, flags=flags)
@@ -33,7 +35,7 @@ s = s.cpu().numpy(); st = st.cpu().numpy()
 steps = s[_abi.SUM_STEPS]
 ff = ((st & 0xFF) == 0) & ((st & _abi.ST_NAN) != 0)
 ps = np.where(ff, np.nan, steps)
-print(f"n={a.n} prec={a.precision} flight_ms={fl:.2f} rail_ms={rail:.3f} physics_steps={phys:.0f} wave_iters={wi:.0f} util={phys/(64*wi):.3f}")
+print(f"chunk={a.chunk} n={a.n} prec={a.precision} flight_ms={fl:.2f} rail_ms={rail:.3f} physics_steps={phys:.0f} wave_iters={wi:.0f} util={phys/(64*wi):.3f}")
 print(f"  per wave-iteration (2048-wave-equivalent): {fl*1e3/(wi/ (a.n/64)):.3f} us per step per wave if all waves concurrent")
 print("  fast-forwarded (NaN) fraction:", ff.mean())
 q = np.nanpercentile(ps, [1, 10, 50, 90, 95, 98, 99, 99.9, 100])
