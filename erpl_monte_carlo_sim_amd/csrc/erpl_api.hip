@@ -296,6 +296,7 @@ int erpl_mc_run_batch(erpl_ctx* c, const erpl_batch* b, const erpl_out* o, void*
   if (!c->has_cfg) return fail(ERPL_ERR_CONFIG, "erpl_mc_set_config has not been called");
   if (b->n < 0) return fail(ERPL_ERR_INVALID, "negative batch size");
   if (b->n == 0) return ERPL_OK;
+  if (b->n > 2147483647LL) return fail(ERPL_ERR_INVALID, "at most 2^31 - 1 samples per batch");
   if (b->precision != ERPL_PREC_F64 && b->precision != ERPL_PREC_F32)
     return fail(ERPL_ERR_INVALID, "unknown precision %d", b->precision);
   if (b->k_wind < 0 || b->k_wind > ERPL_MAX_WIND_KNOTS)

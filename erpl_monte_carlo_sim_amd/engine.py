@@ -37,6 +37,16 @@ class DeviceBatch:
             raise _abi.ErplError("altitude_profile must be strictly increasing")
         if hb.k_wind and not (np.all(np.isfinite(hb.wind)) and np.all(np.isfinite(hb.alt_grid))):
             raise _abi.ErplError("wind profile must be finite")
+        # The kernels assume what the reference silently assumes: finite inputs, positive masses and
+        # mass flow, a finite burn time (a non-finite burn time would never leave the launch rail).
+        if hb.n >= 2 ** 31:
+            raise _abi.ErplError("at most 2**31 - 1 samples per batch")
+        if not (np.all(np.isfinite(hb.ic)) and np.all(np.isfinite(hb.rocket)) and np.all(np.isfinite(hb.motor))):
+            raise _abi.ErplError("initial conditions, masses and motor parameters must be finite")
+        if not (np.all(hb.rocket[0] > 0) and np.all(hb.rocket[1] > 0)):
+            raise _abi.ErplError("dry_mass and propellant_mass must be positive")
+        if not (np.all(hb.motor[2] > 0) and np.all(hb.motor[3] >= 0)):
+            raise _abi.ErplError("mass_flow_rate must be positive and burn_time non-negative")
         wdt = torch.float64 if precision == _abi.PREC_F64 else torch.float32
         f64 = dict(dtype=torch.float64, device=device)
         ic = torch.as_tensor(np.ascontiguousarray(hb.ic), **f64)

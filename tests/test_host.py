@@ -193,3 +193,19 @@ def test_product_never_touches_oracle():
             if f.endswith((".py", ".hip", ".inc", ".h", ".cpp")) or f == "Makefile":
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"(import|from)\s+oracle|liberpl_oracle|oracle/", txt), f
+
+
+def test_device_batch_validation_rejects_bad_inputs():
+    """Boundary validation happens on the host before anything is uploaded (no GPU needed to fail)."""
+    from erpl_monte_carlo_sim_amd.engine import DeviceBatch
+    good = flatten.single_flight_batch(models.Rocket(), models.LiquidMotor(), H.EXAMPLE_IC, H.CSV_WIND, H.CSV_ALT)
+    cases = []
+    b = good.take([0]); b.rocket[0, 0] = -1.0; cases.append(b)
+    b = good.take([0]); b.motor[2, 0] = 0.0; cases.append(b)
+    b = good.take([0]); b.motor[3, 0] = float("inf"); cases.append(b)
+    b = good.take([0]); b.ic[2, 0] = float("nan"); cases.append(b)
+    b = good.take([0]); b.wind[1, 0, 0] = float("nan"); cases.append(b)
+    b = good.take([0]); b.alt_grid[2] = b.alt_grid[1]; cases.append(b)
+    for bad in cases:
+        with pytest.raises(_abi.ErplError):
+            DeviceBatch.from_host(bad, "cpu")
