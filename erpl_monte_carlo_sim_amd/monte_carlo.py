@@ -14,7 +14,7 @@ import time
 import numpy as np
 import torch
 
-from . import _abi, analysis, dist, flatten
+from . import _abi, analysis, dist, flatten, reports
 from .engine import DeviceBatch
 from .sampling import DEFAULT_UNCERTAINTY
 from .simulator import shared_engine
@@ -165,6 +165,14 @@ class MonteCarloAnalyzer:
 
     def run_optimized_monte_carlo(self, initial_conditions, n_samples=1000, chunk_size=None):
         return self.run_monte_carlo(initial_conditions, n_samples, optimized=True)
+
+    def _create_output_directory(self):
+        """monte_carlo.py:475-480."""
+        return reports.create_output_directory()
+
+    def _save_report(self, analysis, output_dir):
+        """monte_carlo.py:482-560 (same files, keys and text format)."""
+        return reports.save_report(self, analysis, output_dir)
 
     def _filter_physics_outliers(self, results):
         """monte_carlo.py:337-398."""

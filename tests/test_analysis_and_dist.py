@@ -80,6 +80,34 @@ def test_device_statistics_equal_host_statistics():
         analysis.device_statistics(torch.full((16, 4), float("nan"), dtype=torch.float64))
 
 
+def test_report_writer_matches_reference_format(tmp_path):
+    """monte_carlo_report.txt / .json in the reference's on-disk format: the statistics block of one of
+    the reference's own committed reports must render to the very same text lines."""
+    import json
+    from erpl_monte_carlo_sim_amd import reports
+    g = H.load_json("report_format.json")
+
+    class A:  # the four objects + uncertainty table a MonteCarloAnalyzer carries
+        rocket, motor = models.Rocket(), models.LiquidMotor()
+        atmosphere, wind_model = models.StandardAtmosphere(), models.WindModel()
+        uncertainty_params = H.UNCERTAINTY
+
+    analysis = dict(g["analysis"])
+    analysis["results"] = [{"simulation_id": 7, "apogee_altitude": np.float64(1.5), "trajectory": {"time": np.arange(3.0)}}]
+    rep = reports.save_report(A, analysis, str(tmp_path))
+    assert rep["simulation_summary"]["success_rate"] == g["success_rate"]
+    txt = open(tmp_path / "monte_carlo_report.txt").read().split("\n")
+    assert [l for l in txt if not l.startswith("Generated:")] == g["txt_lines"]
+    on_disk = json.load(open(tmp_path / "monte_carlo_report.json"))
+    assert list(on_disk.keys()) == g["json_keys"]
+    sim = json.load(open(tmp_path / "simulation_results" / "sim_7.json"))
+    assert sim["trajectory"]["time"] == [0.0, 1.0, 2.0]
+    # with a performance block (run_optimized_monte_carlo, monte_carlo.py:555-560)
+    analysis["performance"] = {"total_time": 1.234, "simulations_per_second": 1e6, "cores_used": 16}
+    lines = reports.report_text(reports.build_report(A, analysis))
+    assert "  Simulations per second: 1000000.0" in lines and "  Cores used: 16" in lines
+
+
 def test_shard_bounds_cover_everything():
     for n in (0, 1, 7, 8, 9, 1000, 131072):
         for ws in (1, 2, 3, 8):
