@@ -4,5 +4,5 @@ args="$1"; shift
 for lib in "$@"; do
   cp "$lib" erpl_monte_carlo_sim_amd/csrc/liberpl_mc.so
   echo "== $lib $args"
-  timeout -k 10 200 python tools/diag_steps.py $args 2>&1 | grep -E "^n="
+  timeout -k 10 200 python tools/diag_steps.py $args 2>&1 | grep -E "^chunk="
 done
