@@ -197,6 +197,26 @@ def test_fp32_first_apogee_within_0p1_percent(engine, oracle):
     assert np.max(relerr(summ[_abi.SUM_RAIL_EXIT_SPEED], osum[_abi.SUM_RAIL_EXIT_SPEED])) < 2e-5
 
 
+@pytest.mark.parametrize("kind,base", [("solid", "csv"), ("liquid", "none"), ("solid", "none"), ("liquid", "nowind")])
+def test_fp32_kernel_specialisations(engine, oracle, kind, base):
+    """The fp32 flight kernel is compiled in four specialisations (wind table present or not x
+    liquid / solid motor, chosen by the launcher): each one against the oracle, same 0.1 % bar."""
+    hb = mc_batch(kind, 192, base="none" if base == "nowind" else base, planar=True)
+    if base == "nowind":  # k_wind = 0: the RHS sees still air (simulate_flight without a profile)
+        hb0 = flatten.HostBatch(hb.n, 0)
+        hb0.ic, hb0.rocket, hb0.motor = hb.ic, hb.rocket, hb.motor
+        hb = hb0
+    cfg = H.make_config(kind)
+    summ, status = run_gpu(engine, cfg, hb, prec=_abi.PREC_F32, flags=_abi.FLAG_STOP_AT_APOGEE)
+    osum, ostat = oracle.run_batch(cfg, hb, flags=_abi.FLAG_STOP_AT_APOGEE)
+    assert np.array_equal(status & 0xFF, ostat & 0xFF)
+    e = relerr(summ[_abi.SUM_FIRST_APOGEE_ALT], osum[_abi.SUM_FIRST_APOGEE_ALT])
+    print(f"fp32 {kind}/{base}: first-apogee max rel err {e.max():.2e}")
+    assert e.max() < 1e-3
+    assert np.max(relerr(summ[_abi.SUM_MAX_SPEED], osum[_abi.SUM_MAX_SPEED])) < 1e-3
+    assert np.max(np.abs(summ[_abi.SUM_STEPS] - osum[_abi.SUM_STEPS])) <= 25
+
+
 def test_fp32_set_r_match_rate(engine, oracle):
     """Diverging samples: fp32 parity is only meaningful on the first-descent apogee (fact 6)."""
     hb = mc_batch("liquid", 1000)
