@@ -79,6 +79,11 @@ int build_tables(const erpl_config& c, ErplTables& T) {
   }
   if (!(c.dt_initial > 0) || !std::isfinite(c.dt_initial) || !std::isfinite(c.max_time))
     return fail(ERPL_ERR_INVALID, "dt_initial must be positive and finite");
+  // the kernels count steps in int32 and advance time by `t += dt`: a horizon of more than 2^30 steps
+  // overflows the counter, and long before that dt drops below ulp(t) and the loop stops advancing
+  // (the reference would spin for ever there too) - refuse it instead of hanging the GPU
+  if (c.max_time > 0 && c.max_time / ((0.005 < c.dt_initial) ? 0.005 : c.dt_initial) > 1073741824.0)
+    return fail(ERPL_ERR_INVALID, "max_time / dt exceeds 2^30 steps");
 
   ErplScalars<double>& s = T.s64;
   s.dq2 = pow(c.diameter / 4, 2.0);                    // rocket.py:122

@@ -319,6 +319,9 @@ def test_error_paths(engine):
     cfg.cd_mach[1] = float("nan")
     assert lib.erpl_mc_set_config(ctx, C.byref(cfg)) == -1
     cfg = H.make_config("liquid")
+    cfg.dt_initial = 1e-12   # 3e14 steps: int32 step counter / `t += dt` cannot advance -> refused, not hung
+    assert lib.erpl_mc_set_config(ctx, C.byref(cfg)) == -1
+    cfg = H.make_config("liquid")
     assert lib.erpl_mc_set_config(ctx, C.byref(cfg)) == 0
     assert lib.erpl_mc_run_batch(ctx, C.byref(b), C.byref(o), None) == -1  # NULL buffers
     assert b"NULL" in lib.erpl_mc_last_error()
