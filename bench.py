@@ -138,39 +138,54 @@ def main():
         n, rocket, motor, wm, EXAMPLE_IC, device, precision=prec, seed=1234 + rank, planar=planar or csv,
         base_altitude_profile=CSV_ALT if csv else None, base_wind_profile=CSV_WIND if csv else None)
     eng.reserve(n)
-    summary, status = eng.alloc_outputs(n)
-    gathered = gathered_st = None
-    if world > 1:
-        gathered = torch.empty((world * _abi.SUMMARY_DIM, n), dtype=torch.float64, device=device)
-        gathered_st = torch.empty((world * n,), dtype=torch.int32, device=device)
-
     gloo_rehearsal = world > 1 and os.environ.get("ERPL_BENCH_BACKEND", "nccl") != "nccl"
+    # N > 1: the all-gather of pass i (RCCL over xGMI, on RCCL's own stream) overlaps the kernels of pass
+    # i+1, so outputs and gather buffers are double-buffered; every gather issued inside the timed region
+    # is waited for before the closing barrier.
+    nbuf = 2 if world > 1 else 1
+    outs = [eng.alloc_outputs(n) for _ in range(nbuf)]
+    gath = []
+    for _ in range(nbuf if world > 1 else 0):
+        gdev = "cpu" if gloo_rehearsal else device
+        gath.append((torch.empty((world * _abi.SUMMARY_DIM, n), dtype=torch.float64, device=gdev),
+                     torch.empty((world * n,), dtype=torch.int32, device=gdev)))
+    pending = [None] * nbuf
 
-    def step():
-        eng.run(db, flags=flags, summary=summary, status=status)
-        if world > 1:  # RCCL all-gather of the per-sample summaries over xGMI (monte_carlo.py:76-83)
+    def wait_gather(k):
+        if pending[k] is not None:
+            for w in pending[k]:
+                w.wait()
+            pending[k] = None
+
+    def step(i):
+        k = i % nbuf
+        wait_gather(k)  # the gather that last read these output buffers
+        s_k, t_k = outs[k]
+        eng.run(db, flags=flags, summary=s_k, status=t_k)
+        if world > 1:  # all-gather of the per-sample summaries (monte_carlo.py:76-83)
+            g_s, g_t = gath[k]
             if gloo_rehearsal:
                 torch.cuda.synchronize()
-                hs, ht = summary.cpu(), status.cpu()
-                gs = torch.empty((world * _abi.SUMMARY_DIM, n), dtype=torch.float64)
-                gt = torch.empty((world * n,), dtype=torch.int32)
-                dist.all_gather_into_tensor(gs, hs)
-                dist.all_gather_into_tensor(gt, ht)
-                gathered.copy_(gs); gathered_st.copy_(gt)
-            else:
-                dist.all_gather_into_tensor(gathered, summary)
-                dist.all_gather_into_tensor(gathered_st, status)
+                s_k, t_k = s_k.cpu(), t_k.cpu()
+            pending[k] = [dist.all_gather_into_tensor(g_s, s_k, async_op=True),
+                          dist.all_gather_into_tensor(g_t, t_k, async_op=True)]
+
+    def drain():
+        for k in range(nbuf):
+            wait_gather(k)
 
     eng.set_profiling(True)
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -180,6 +195,13 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo_rehearsal else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    summary, status = outs[(args.steps - 1) % nbuf]
+    if world > 1:  # every rank must hold every rank's summaries: rank-major rows, own block == own results
+        g_s, g_t = gath[(args.steps - 1) % nbuf]
+        own = g_s[rank * _abi.SUMMARY_DIM:(rank + 1) * _abi.SUMMARY_DIM].to(summary.device)
+        if not bool(((own == summary) | (own.isnan() & summary.isnan())).all()) or \
+                not torch.equal(g_t[rank * n:(rank + 1) * n].to(status.device), status):
+            raise SystemExit("all-gather result does not contain this rank's summaries")
 
     rail_ms, flight_ms = eng.kernel_ms_history(args.steps)
     phys_steps, wave_iters = eng.last_stats()
@@ -192,7 +214,7 @@ def main():
     pipelined = None
     if world == 1 and args.pipeline > 1:
         engs = [eng] + [TrajectoryEngine(device) for _ in range(args.pipeline - 1)]
-        outs = [(summary, status)] + [eng.alloc_outputs(n) for _ in range(args.pipeline - 1)]
+        pouts = [(summary, status)] + [eng.alloc_outputs(n) for _ in range(args.pipeline - 1)]
         streams = [torch.cuda.Stream(device) for _ in range(args.pipeline)]
         for e in engs[1:]:
             e.set_config(cfg); e.set_launch(args.block, args.max_blocks, args.refill); e.reserve(n)
@@ -200,12 +222,12 @@ def main():
                 e.set_chunk(args.chunk)
         for k in range(args.pipeline):       # warm-up of the extra contexts
             with torch.cuda.stream(streams[k]):
-                engs[k].run(db, flags=flags, summary=outs[k][0], status=outs[k][1], stream=streams[k])
+                engs[k].run(db, flags=flags, summary=pouts[k][0], status=pouts[k][1], stream=streams[k])
         torch.cuda.synchronize()
         tp = time.perf_counter()
         for i in range(args.steps):
             k = i % args.pipeline
-            engs[k].run(db, flags=flags, summary=outs[k][0], status=outs[k][1], stream=streams[k])
+            engs[k].run(db, flags=flags, summary=pouts[k][0], status=pouts[k][1], stream=streams[k])
         torch.cuda.synchronize()
         el_p = time.perf_counter() - tp
         pipelined = {"depth": args.pipeline, "value": n * args.steps / el_p, "unit": "trajectories/s",
@@ -250,7 +272,7 @@ def main():
                             f"rail dt=0.01 + RK4 dt=0.005, "
                             f"{'to first-descent apogee' if flags else 'full reference termination logic'}",
                 "samples_per_gpu": n, "precision": args.precision,
-                "parallelism": f"sample-shard x{world}" + (" + RCCL all-gather of [16,n] summaries" if world > 1 else ""),
+                "parallelism": f"sample-shard x{world}" + (" + RCCL all-gather of [16,n] summaries overlapped with the next pass" if world > 1 else ""),
             },
             "trajectory_steps_per_s": phys_total * args.steps / elapsed,
             "steps_per_trajectory": {"mean": float(steps_col.mean()), "max": float(steps_col.max()),
