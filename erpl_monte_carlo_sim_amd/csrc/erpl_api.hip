@@ -123,6 +123,8 @@ int build_tables(const erpl_config& c, ErplTables& T) {
   s.k_meso = s.g0 * M_LOG2E / s.Rg;
   s.two_pi_AR_cos = s.two_pi_AR * s.cos_sweep;
   s.area_diam = s.ref_area * s.ref_diam;
+  s.AR_over_cos2 = s.AR_over_cos * s.AR_over_cos;
+  s.q_of_PM2 = 0.5 * (1.4 * 287.053) / s.Rg;
   s.chute_k = 0.5 * s.chute_cd * s.chute_area;
   convert_scalars(T.s64, T.s32);
   T.dt_rail = s.dt_rail; T.dt_flight = s.dt_flight; T.max_time = s.max_time;

@@ -44,7 +44,9 @@
   X(k_meso)         /* g*log2(e)/R               : mesosphere scale-height term */               \
   X(two_pi_AR_cos)  /* 2*pi*AR*cos(sweep) */                                                     \
   X(area_diam)      /* reference_area * reference_diameter */                                    \
-  X(chute_k)        /* 0.5 * parachute_cd * parachute_area */
+  X(chute_k)        /* 0.5 * parachute_cd * parachute_area */                                    \
+  X(AR_over_cos2)   /* (AR / cos_sweep_c)^2 */                                                   \
+  X(q_of_PM2)       /* 0.5 * (1.4 * 287.053) / R : q_dynamic = q_of_PM2 * P * Mach^2 */
 
 template <typename R>
 struct ErplScalars {
