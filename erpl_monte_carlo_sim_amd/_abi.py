@@ -83,10 +83,13 @@ LIB_NAME = "liberpl_mc.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
 
 # every symbol include/erpl_mc.h declares
+RS_GAUSS, RS_DOUBLE = 0, 1   # erpl_mc_legacy_random_streams ops
+
 EXPORTS = ("erpl_mc_abi_version", "erpl_mc_last_error", "erpl_mc_create", "erpl_mc_destroy",
            "erpl_mc_set_config", "erpl_mc_reserve", "erpl_mc_run_batch", "erpl_mc_set_launch",
            "erpl_mc_last_stats", "erpl_mc_set_profiling", "erpl_mc_last_kernel_ms",
-           "erpl_mc_kernel_ms_history", "erpl_mc_debug_counters", "erpl_mc_extract_histories", "erpl_mc_set_chunk")
+           "erpl_mc_kernel_ms_history", "erpl_mc_debug_counters", "erpl_mc_extract_histories", "erpl_mc_set_chunk",
+           "erpl_mc_legacy_random_streams")
 
 _lib = None
 

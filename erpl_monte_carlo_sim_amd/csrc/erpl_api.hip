@@ -390,6 +390,82 @@ int erpl_mc_last_kernel_ms(erpl_ctx* c, float* rail_ms, float* flight_ms) {
   return erpl_mc_kernel_ms_history(c, 1, rail_ms, flight_ms, &n);
 }
 
+// ------------------------------------------------------------------ legacy RandomState streams
+// MT19937 seeded like numpy.random.RandomState(int) (init_genrand), 53-bit doubles and the polar
+// gaussian with its one-value cache - the published algorithms of the generator the reference draws
+// from (monte_carlo.py:157 `np.random.RandomState(i)`).  Host code; built without FMA contraction so
+// that x1*x1 + x2*x2 rounds like the baseline x86-64 build of NumPy.
+namespace {
+struct LegacyRS {
+  uint32_t key[624];
+  int pos;
+  bool has_gauss;
+  double gauss;
+  void seed(uint32_t s) {
+    for (int i = 0; i < 624; ++i) { key[i] = s; s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)i + 1u; }
+    pos = 624; has_gauss = false; gauss = 0.0;
+  }
+  void refill() {
+    const uint32_t A = 0x9908b0dfu, UP = 0x80000000u, LO = 0x7fffffffu;
+    int k = 0;
+    for (; k < 624 - 397; ++k) { uint32_t y = (key[k] & UP) | (key[k + 1] & LO); key[k] = key[k + 397] ^ (y >> 1) ^ ((y & 1u) ? A : 0u); }
+    for (; k < 623; ++k) { uint32_t y = (key[k] & UP) | (key[k + 1] & LO); key[k] = key[k + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? A : 0u); }
+    uint32_t y = (key[623] & UP) | (key[0] & LO);
+    key[623] = key[396] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+    pos = 0;
+  }
+  uint32_t next32() {
+    if (pos == 624) refill();
+    uint32_t y = key[pos++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+  }
+  double next_double() {
+    const uint32_t a = next32() >> 5, b = next32() >> 6;
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+  }
+  double next_gauss() {
+    if (has_gauss) { const double g = gauss; has_gauss = false; gauss = 0.0; return g; }
+    double x1, x2, r2;
+    do {
+      x1 = 2.0 * next_double() - 1.0;
+      x2 = 2.0 * next_double() - 1.0;
+      r2 = x1 * x1 + x2 * x2;
+    } while (r2 >= 1.0 || r2 == 0.0);
+    const double f = sqrt(-2.0 * log(r2) / r2);
+    gauss = f * x1; has_gauss = true;
+    return f * x2;
+  }
+};
+}  // namespace
+
+int erpl_mc_legacy_random_streams(const uint32_t* seeds, int64_t n, const uint8_t* ops, int32_t m,
+                                  double* out, int32_t by_output, int32_t threads) {
+  if (n < 0 || m < 0) return fail(ERPL_ERR_INVALID, "negative size");
+  if (n == 0 || m == 0) return ERPL_OK;
+  if (!seeds || !ops || !out) return fail(ERPL_ERR_INVALID, "NULL buffer");
+  for (int32_t j = 0; j < m; ++j)
+    if (ops[j] != ERPL_RS_GAUSS && ops[j] != ERPL_RS_DOUBLE) return fail(ERPL_ERR_INVALID, "unknown stream op %d", (int)ops[j]);
+  int nthr = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+  if (nthr < 1) nthr = 1;
+  if ((int64_t)nthr > n) nthr = (int)n;
+  auto work = [&](int w) {
+    LegacyRS rs;
+    const int64_t lo = n * w / nthr, hi = n * (w + 1) / nthr;
+    for (int64_t i = lo; i < hi; ++i) {
+      rs.seed(seeds[i]);
+      double* o = by_output ? out + i : out + i * (int64_t)m;
+      const int64_t stride = by_output ? n : 1;
+      for (int32_t j = 0; j < m; ++j) o[j * stride] = (ops[j] == ERPL_RS_GAUSS) ? rs.next_gauss() : rs.next_double();
+    }
+  };
+  if (nthr == 1) { work(0); return ERPL_OK; }
+  std::vector<std::thread> pool;
+  for (int w = 0; w < nthr; ++w) pool.emplace_back(work, w);
+  for (auto& t : pool) t.join();
+  return ERPL_OK;
+}
+
 int erpl_mc_extract_histories(erpl_ctx* c, const erpl_batch* b, int64_t sample, const double* traj, int64_t m,
                               double time_offset, double* out, void* stream) {
   if (!c || !b || !traj || !out) return fail(ERPL_ERR_INVALID, "NULL argument");

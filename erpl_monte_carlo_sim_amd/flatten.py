@@ -148,8 +148,9 @@ def single_flight_batch(rocket, motor, initial_conditions, wind_profile, altitud
     return b
 
 
-def generate_parameter_samples(uncertainty, n_samples, stream="seed_i"):
-    """The dispersion draws of monte_carlo.py:156-179 (`stream='seed_i'`: RandomState(i) per
+def generate_parameter_samples_loop(uncertainty, n_samples, stream="seed_i"):
+    """Per-sample Python restatement (kept as the cross-check of the vectorised path): the dispersion
+    draws of monte_carlo.py:156-179 (`stream='seed_i'`: RandomState(i) per
     sample) or :181-201 (`stream='seed_42'`: one RandomState(42) stream).  Same calls in the same
     order on the legacy generator, so the values are bit-identical to the reference's."""
     u = uncertainty
@@ -173,9 +174,9 @@ def generate_parameter_samples(uncertainty, n_samples, stream="seed_i"):
     return out
 
 
-def dispersed_batch(rocket, motor, wind_model, base_initial_conditions, params_list,
-                    base_altitude_profile=None, base_wind_profile=None, planar=False):
-    """Per-sample inputs exactly as MonteCarloAnalyzer._run_single_simulation builds them
+def dispersed_batch_loop(rocket, motor, wind_model, base_initial_conditions, params_list,
+                         base_altitude_profile=None, base_wind_profile=None, planar=False):
+    """Per-sample Python restatement (kept as the cross-check of the vectorised path).  Per-sample inputs exactly as MonteCarloAnalyzer._run_single_simulation builds them
     (monte_carlo.py:228-288): IC + offsets, masses x mass_multiplier, motor perturbed from a
     fresh RandomState(seed) with propellant mass / burn time re-synchronised (:258-260), wind
     from another fresh RandomState(seed) (CSV baseline + AR(1) + uniform offset, or the 100-knot
@@ -228,3 +229,204 @@ def dispersed_batch(rocket, motor, wind_model, base_initial_conditions, params_l
                 w[:, 1] = 0.0
         b.wind[:, :, i] = w
     return b
+
+
+# ---------------------------------------------------------------------------------- vectorised
+# The same constructions for all samples at once.  The per-sample legacy RandomState(seed) streams
+# come from the C ABI (erpl_mc_legacy_random_streams, bit-identical to NumPy's generator); the
+# arithmetic on them is the reference's, element for element, as NumPy array expressions - IEEE
+# +,-,*,/ and sqrt do not depend on the array shape, and np.cos / np.sin / np.exp give the same bits
+# for an array element as for a scalar call (checked by tests/test_host.py against the per-sample
+# loops above and against the reference's own captured inputs); `**` does not, so powers are taken
+# on scalars exactly where the reference takes them on scalars.
+_PARAM_OPS = "g" * 14 + "uu" + "g"   # pos3 vel3 att3 omega3 mass thrust | wind speed, direction | density
+
+
+def legacy_streams(seeds, ops, threads=0, by_output=False):
+    """First len(ops) outputs ('g' normal / 'u' uniform double) of np.random.RandomState(seed) for
+    every seed: float64 [n, len(ops)], or [len(ops), n] with by_output=True."""
+    import ctypes as C
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+    code = np.frombuffer(ops.encode(), dtype=np.uint8)
+    code = np.ascontiguousarray(np.where(code == ord("g"), _abi.RS_GAUSS, _abi.RS_DOUBLE).astype(np.uint8))
+    out = np.empty((code.size, seeds.size) if by_output else (seeds.size, code.size), dtype=np.float64)
+    lib = _abi.load_library()
+    _abi.check(lib, lib.erpl_mc_legacy_random_streams(
+        seeds.ctypes.data_as(C.c_void_p), C.c_int64(seeds.size), code.ctypes.data_as(C.c_void_p),
+        C.c_int32(code.size), out.ctypes.data_as(C.c_void_p), C.c_int32(1 if by_output else 0), C.c_int32(threads)),
+        "erpl_mc_legacy_random_streams")
+    return out
+
+
+def generate_parameter_arrays(uncertainty, n_samples):
+    """monte_carlo.py:156-179 for samples 0..n-1 (RandomState(i) each) as arrays: dict of [n, 3] /
+    [n] float64 plus "random_seed"."""
+    u = uncertainty
+    r = legacy_streams(np.arange(n_samples, dtype=np.uint32), _PARAM_OPS)
+    sc = lambda key: np.asarray(u[key], dtype=np.float64)[None, :]
+    lo_s, hi_s = u["wind_speed_range"]
+    lo_d, hi_d = u["wind_direction_range"]
+    return {
+        "initial_position_offset": 0.0 + sc("initial_position") * r[:, 0:3],
+        "initial_velocity_offset": 0.0 + sc("initial_velocity") * r[:, 3:6],
+        "initial_attitude_offset": 0.0 + sc("initial_attitude") * r[:, 6:9],
+        "initial_angular_velocity_offset": 0.0 + sc("initial_angular_velocity") * r[:, 9:12],
+        "mass_multiplier": 1.0 + u["mass_uncertainty"] * r[:, 12],
+        "thrust_multiplier": 1.0 + u["thrust_uncertainty"] * r[:, 13],
+        "wind_speed": lo_s + (hi_s - lo_s) * r[:, 14],
+        "wind_direction": lo_d + (hi_d - lo_d) * r[:, 15],
+        "density_multiplier": 1.0 + u["atmospheric_density_uncertainty"] * r[:, 16],
+        "random_seed": np.arange(n_samples, dtype=np.int64),
+    }
+
+
+_VEC_KEYS = ("initial_position_offset", "initial_velocity_offset", "initial_attitude_offset",
+             "initial_angular_velocity_offset")
+_SCALAR_KEYS = ("mass_multiplier", "thrust_multiplier", "wind_speed", "wind_direction", "density_multiplier")
+
+
+def generate_parameter_samples(uncertainty, n_samples, stream="seed_i"):
+    """The dispersion draws of monte_carlo.py:156-179 (`stream='seed_i'`: RandomState(i) per
+    sample) or :181-201 (`stream='seed_42'`: one RandomState(42) stream) as the reference's list of
+    per-sample dicts, bit-identical to the reference's values."""
+    if stream == "seed_42":   # one sequential stream: nothing to spread over samples
+        return generate_parameter_samples_loop(uncertainty, n_samples, stream)
+    a = generate_parameter_arrays(uncertainty, n_samples)
+    out = []
+    for i in range(n_samples):
+        d = {k: a[k][i].copy() for k in _VEC_KEYS}
+        d.update({k: float(a[k][i]) for k in _SCALAR_KEYS})
+        d["random_seed"] = i
+        out.append(d)
+    return out
+
+
+def params_to_arrays(params_list):
+    """List of per-sample dicts -> the array form of generate_parameter_arrays."""
+    a = {k: np.array([p[k] for p in params_list], dtype=np.float64).reshape(len(params_list), 3) for k in _VEC_KEYS}
+    a.update({k: np.array([p[k] for p in params_list], dtype=np.float64) for k in _SCALAR_KEYS if k in params_list[0]})
+    a["random_seed"] = np.array([p["random_seed"] for p in params_list], dtype=np.int64)
+    return a
+
+
+def _ar1_profiles(wind_model, alt, g, mean_u=None, mean_v=None, base=None):
+    """AR(1) turbulence of environment.py:161-198 / :242-263 for all samples: g [3K, n] holds each
+    sample's normals in draw order (u, v, w per knot); returns [K, 3, n]."""
+    sigma, rho, innov = wind_model._knot_constants(alt)
+    K, n = len(sigma), g.shape[1]
+    out = np.empty((K, 3, n))
+    zero = np.zeros(n)
+    mu = (lambda k: mean_u[k]) if mean_u is not None else (lambda k: base[k, 0])
+    mv = (lambda k: mean_v[k]) if mean_v is not None else (lambda k: base[k, 1])
+    mw = (lambda k: zero) if base is None else (lambda k: base[k, 2])
+    out[0, 0] = mu(0) + (0.0 + sigma[0] * g[0])
+    out[0, 1] = mv(0) + (0.0 + sigma[0] * g[1])
+    w0 = 0.0 + (sigma[0] * 0.3) * g[2]
+    out[0, 2] = w0 if base is None else mw(0) + w0
+    for i in range(1, K):
+        pu = out[i - 1, 0] - mu(i - 1)
+        pv = out[i - 1, 1] - mv(i - 1)
+        pw = out[i - 1, 2] if base is None else out[i - 1, 2] - mw(i - 1)
+        tu = rho[i] * pu + (0.0 + innov[i] * g[3 * i])
+        tv = rho[i] * pv + (0.0 + innov[i] * g[3 * i + 1])
+        tw = rho[i] * pw + (0.0 + (innov[i] * 0.3) * g[3 * i + 2])
+        out[i, 0] = mu(i) + tu
+        out[i, 1] = mv(i) + tv
+        out[i, 2] = tw if base is None else mw(i) + tw
+    return out
+
+
+def dispersed_batch(rocket, motor, wind_model, base_initial_conditions, params_list,
+                    base_altitude_profile=None, base_wind_profile=None, planar=False):
+    """Per-sample inputs exactly as MonteCarloAnalyzer._run_single_simulation builds them
+    (monte_carlo.py:228-288), for all samples at once: IC + offsets, masses x mass_multiplier, motor
+    perturbed from a fresh RandomState(seed) with propellant mass / burn time re-synchronised
+    (:258-260), wind from another fresh RandomState(seed) (CSV baseline + AR(1) + uniform offset, or
+    the 100-knot synthetic profile).  `planar=True` zeroes every out-of-plane input (Set P, SURVEY
+    §8d).  `params_list` is the reference's list of dicts or the dict of arrays of
+    generate_parameter_arrays."""
+    use_base = base_wind_profile is not None and base_altitude_profile is not None
+    alt = (np.asarray(base_altitude_profile, dtype=np.float64) if use_base else np.linspace(0, 25000, 100))
+    if not isinstance(params_list, dict) and len(params_list) == 0:
+        b = HostBatch(0, len(alt))
+        b.alt_grid[:] = alt
+        return b
+    P = params_list if isinstance(params_list, dict) else params_to_arrays(params_list)
+    seeds = np.asarray(P["random_seed"])
+    n = seeds.size
+    if seeds.min() < 0 or seeds.max() > 0xFFFFFFFF:
+        raise UnsupportedModel("random_seed must fit an unsigned 32-bit integer (np.random.RandomState(int))")
+    b = HostBatch(n, len(alt))
+    b.alt_grid[:] = alt
+    ic0 = base_initial_conditions
+
+    def off(key, pkey):   # np.array(ic0[key]) + offset, or the offset alone (monte_carlo.py:228-249)
+        return (np.array(ic0[key], dtype=np.float64)[None, :] + P[pkey]) if key in ic0 else P[pkey]
+    pos = off("position", "initial_position_offset")
+    vel = off("velocity", "initial_velocity_offset")
+    att = off("attitude", "initial_attitude_offset")
+    omg = off("angular_velocity", "initial_angular_velocity_offset")
+    if planar:
+        base_v = np.array(ic0.get("velocity", [0.0, 0.0, 0.0]), dtype=np.float64)[None, :]
+        base_a = np.array(ic0.get("attitude", [0.0, 0.0, 0.0]), dtype=np.float64)[None, :]
+        vel = base_v + P["initial_velocity_offset"] * np.array([1, 0, 1])[None, :]
+        att = base_a + P["initial_attitude_offset"] * np.array([0, 1, 0])[None, :]
+        omg = P["initial_angular_velocity_offset"] * np.array([0, 1, 0])[None, :]
+    b.ic[0:3] = pos.T
+    b.ic[3:6] = vel.T
+    b.ic[6:10] = euler_to_quaternion(att[:, 0], att[:, 1], att[:, 2])
+    b.ic[10:13] = omg.T
+    dry = rocket.dry_mass * P["mass_multiplier"]
+    prop = rocket.propellant_mass * P["mass_multiplier"]
+    b.rocket[0], b.rocket[1] = dry, prop
+
+    # motor perturbation from a fresh RandomState(seed) (motor.py:95-125 / :171-186)
+    if motor_kind(motor) == _abi.MOTOR_SOLID:
+        g = legacy_streams(seeds, "ggg")   # thrust, burn time, impulse (the last two: drawn, then overwritten/unused)
+        k = 1.0 + motor.thrust_uncertainty * g[:, 0]
+        mdot = 4.26 * k
+        b.motor[0] = k
+        b.motor[1] = motor.nozzle_exit_area * k
+    else:
+        g = legacy_streams(seeds, "gg")    # thrust, mass flow
+        k = 1.0 + motor.thrust_uncertainty * g[:, 0]
+        kf = 1.0 + motor.mass_flow_uncertainty * g[:, 1]
+        tv = motor.thrust_vacuum * k
+        mdot = motor.mass_flow_rate * kf
+        b.motor[0] = tv
+        b.motor[1] = (tv - motor.thrust_sea_level * k) / 101325.0
+    if not np.all(mdot > 0):   # the re-synchronisation of :258-260 is conditional on a positive mass flow
+        return dispersed_batch_loop(rocket, motor, wind_model, base_initial_conditions,
+                                    _arrays_to_params(P), base_altitude_profile, base_wind_profile, planar)
+    b.motor[2] = mdot
+    b.motor[3] = prop / mdot
+
+    # wind from another fresh RandomState(seed)
+    g = legacy_streams(seeds, "g" * (3 * len(alt)), by_output=True)
+    speed, direction = P["wind_speed"], P["wind_direction"]
+    cd, sd = np.cos(direction), np.sin(direction)
+    if use_base:
+        w = _ar1_profiles(wind_model, alt, g, base=np.asarray(base_wind_profile, dtype=np.float64))
+        w[:, 0, :] += speed * cd
+        if planar:
+            w[:, 1, :] = 0.0
+        else:
+            w[:, 1, :] += speed * sd
+    else:
+        mean = [speed * ((np.float64(a) / 10.0) ** wind_model.power_law_exponent) for a in alt]   # environment.py:118-123
+        w = _ar1_profiles(wind_model, alt, g, mean_u=[m * cd for m in mean], mean_v=[m * sd for m in mean])
+        if planar:
+            w[:, 1, :] = 0.0
+    b.wind = w
+    return b
+
+
+def _arrays_to_params(P):
+    n = len(P["random_seed"])
+    out = []
+    for i in range(n):
+        d = {k: P[k][i].copy() for k in _VEC_KEYS}
+        d.update({k: float(P[k][i]) for k in _SCALAR_KEYS if k in P})
+        d["random_seed"] = int(P["random_seed"][i])
+        out.append(d)
+    return out

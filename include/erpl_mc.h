@@ -200,6 +200,19 @@ int erpl_mc_last_stats(erpl_ctx* ctx, double* total_steps, double* wave_iteratio
 int erpl_mc_extract_histories(erpl_ctx* ctx, const erpl_batch* batch, int64_t sample, const double* traj,
                               int64_t m, double time_offset, double* out, void* hip_stream);
 
+/* Host-side input preparation (no device work): the first `m` outputs of NumPy's legacy
+ * `np.random.RandomState(seed)` for each of `n` integer seeds, bit for bit - the reference draws
+ * every sample's dispersions, motor perturbation and wind turbulence from such per-sample streams
+ * (monte_carlo.py:157, :253, :263; motor.py:95-125/:171-186; environment.py:161-198/:242-263).
+ * ops[j] selects output j of every stream: ERPL_RS_GAUSS = one standard normal of `normal()` /
+ * `randn()` (polar method, second value cached as the generator does), ERPL_RS_DOUBLE = one
+ * `random_sample()` double in [0,1) as used by `uniform()`.  out (host memory) is [n][m] row-major,
+ * or [m][n] when `by_output` is non-zero (all samples' j-th output contiguous).
+ * Samples are independent, so the work is spread over `threads` host threads (<= 0: all cores). */
+enum { ERPL_RS_GAUSS = 0, ERPL_RS_DOUBLE = 1 };
+int erpl_mc_legacy_random_streams(const uint32_t* seeds, int64_t n, const uint8_t* ops, int32_t m,
+                                  double* out, int32_t by_output, int32_t threads);
+
 /* Raw device counters of the last run_batch (16 doubles): [0] queue head, [1] RK4 steps, [2] wave
  * iterations, [8..15] per-segment s_memtime sums of a -DERPL_STAMPS=1 diagnostic build (0 otherwise). */
 int erpl_mc_debug_counters(erpl_ctx* ctx, double* out16);

@@ -66,6 +66,47 @@ def test_csv_loader(tmp_path):
     assert w.shape == (2, 3) and np.all(w[:, 2] == 0)
 
 
+def test_legacy_random_streams_match_numpy():
+    """erpl_mc_legacy_random_streams == np.random.RandomState(seed) draw for draw (normal / uniform mixed,
+    gaussian cache included), for small, large and 32-bit-limit seeds."""
+    ops = "ggugguugggu" * 30
+    seeds = np.array([0, 1, 2, 41, 42, 999, 123456789, 2**31 - 1, 2**31, 2**32 - 1] + list(range(100, 190)), dtype=np.uint32)
+    got = flatten.legacy_streams(seeds, ops, threads=3)
+    for s, row in zip(seeds, got):
+        rs = np.random.RandomState(int(s))
+        ref = np.array([rs.normal() if o == "g" else rs.random_sample() for o in ops])
+        assert np.array_equal(ref, row), int(s)
+    assert np.array_equal(flatten.legacy_streams(seeds, ops, by_output=True), got.T)
+    assert flatten.legacy_streams(np.zeros(0, dtype=np.uint32), "gg").shape == (0, 2)
+
+
+@pytest.mark.parametrize("kind,base,planar", [("liquid", "csv", False), ("solid", "csv", True),
+                                              ("liquid", "none", True), ("solid", "none", False)])
+def test_vectorised_batch_equals_per_sample_loop(kind, base, planar):
+    """The all-samples-at-once host preparation is bit-identical to the per-sample restatement of
+    monte_carlo.py:228-288 (which the tests below pin to the reference's own captured inputs)."""
+    n = 150
+    assert flatten.generate_parameter_samples(H.UNCERTAINTY, 40)[7]["wind_speed"] == \
+        flatten.generate_parameter_samples_loop(H.UNCERTAINTY, 40)[7]["wind_speed"]
+    pl_fast = flatten.generate_parameter_samples(H.UNCERTAINTY, n)
+    pl_loop = flatten.generate_parameter_samples_loop(H.UNCERTAINTY, n)
+    for a, b in zip(pl_fast, pl_loop):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+    kw = dict(base_altitude_profile=H.CSV_ALT, base_wind_profile=H.CSV_WIND) if base == "csv" else {}
+    args = (models.Rocket(), H.make_motor(kind), models.WindModel(), H.EXAMPLE_IC)
+    fast = flatten.dispersed_batch(*args, pl_fast, planar=planar, **kw)
+    arr = flatten.dispersed_batch(*args, flatten.generate_parameter_arrays(H.UNCERTAINTY, n), planar=planar, **kw)
+    loop = flatten.dispersed_batch_loop(*args, pl_loop, planar=planar, **kw)
+    for name in ("ic", "rocket", "motor", "alt_grid", "wind"):
+        assert np.array_equal(getattr(fast, name), getattr(loop, name)), name
+        assert np.array_equal(getattr(arr, name), getattr(loop, name)), name
+    sub = flatten.dispersed_batch(*args, [pl_fast[i] for i in (5, 3, 77)], planar=planar, **kw)   # any subset / order
+    assert np.array_equal(sub.wind, loop.wind[:, :, [5, 3, 77]]) and np.array_equal(sub.motor, loop.motor[:, [5, 3, 77]])
+    assert flatten.dispersed_batch(*args, [], **kw).n == 0
+
+
 def _mc_batch(kind, base, stream, ids):
     pl = flatten.generate_parameter_samples(H.UNCERTAINTY, max(ids) + 1, stream=stream)
     pl = [pl[i] for i in ids]
