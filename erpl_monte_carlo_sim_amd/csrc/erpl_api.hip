@@ -448,6 +448,8 @@ int erpl_mc_legacy_random_streams(const uint32_t* seeds, int64_t n, const uint8_
     if (ops[j] != ERPL_RS_GAUSS && ops[j] != ERPL_RS_DOUBLE) return fail(ERPL_ERR_INVALID, "unknown stream op %d", (int)ops[j]);
   int nthr = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
   if (nthr < 1) nthr = 1;
+  if (threads <= 0 && nthr > 32) nthr = 32;   // containers often expose more cores than their quota
+  if ((int64_t)nthr * 64 > n) nthr = (int)((n + 63) / 64);   // at least 64 streams per thread
   if ((int64_t)nthr > n) nthr = (int)n;
   auto work = [&](int w) {
     LegacyRS rs;
