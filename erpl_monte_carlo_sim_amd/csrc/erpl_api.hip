@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -450,7 +451,7 @@ int erpl_mc_legacy_random_streams(const uint32_t* seeds, int64_t n, const uint8_
   if (nthr < 1) nthr = 1;
   if (threads <= 0 && nthr > 32) nthr = 32;   // containers often expose more cores than their quota
   if ((int64_t)nthr * 64 > n) nthr = (int)((n + 63) / 64);   // at least 64 streams per thread
-  if ((int64_t)nthr > n) nthr = (int)n;
+  if (nthr < 1) nthr = 1;
   auto work = [&](int w) {
     LegacyRS rs;
     const int64_t lo = n * w / nthr, hi = n * (w + 1) / nthr;
@@ -465,6 +466,74 @@ int erpl_mc_legacy_random_streams(const uint32_t* seeds, int64_t n, const uint8_
   std::vector<std::thread> pool;
   for (int w = 0; w < nthr; ++w) pool.emplace_back(work, w);
   for (auto& t : pool) t.join();
+  return ERPL_OK;
+}
+
+namespace {
+int host_threads(int32_t requested, int64_t n) {
+  int nthr = requested > 0 ? requested : (int)std::thread::hardware_concurrency();
+  if (nthr < 1) nthr = 1;
+  if (requested <= 0 && nthr > 32) nthr = 32;   // containers often expose more cores than their quota
+  if ((int64_t)nthr * 64 > n) nthr = (int)((n + 63) / 64);   // at least 64 samples per thread
+  return nthr < 1 ? 1 : nthr;
+}
+void run_threads(int nthr, const std::function<void(int)>& work) {
+  if (nthr == 1) { work(0); return; }
+  std::vector<std::thread> pool;
+  for (int w = 0; w < nthr; ++w) pool.emplace_back(work, w);
+  for (auto& t : pool) t.join();
+}
+}  // namespace
+
+int erpl_mc_legacy_wind_profiles(const uint32_t* seeds, int64_t n, int32_t k, const double* sigma,
+                                 const double* rho, const double* innov, const double* base,
+                                 const double* mean_scale, const double* speed, const double* cdir,
+                                 const double* sdir, double* wind, int32_t threads) {
+  if (n < 0 || k < 0) return fail(ERPL_ERR_INVALID, "negative size");
+  if (n == 0 || k == 0) return ERPL_OK;
+  if (!seeds || !sigma || !rho || !innov || !wind) return fail(ERPL_ERR_INVALID, "NULL buffer");
+  if (!base && (!mean_scale || !speed || !cdir || !sdir)) return fail(ERPL_ERR_INVALID, "NULL mean-wind inputs");
+  const int nthr = host_threads(threads, n);
+  run_threads(nthr, [&](int w) {
+    LegacyRS rs;
+    const int64_t lo = n * w / nthr, hi = n * (w + 1) / nthr;
+    for (int64_t s = lo; s < hi; ++s) {
+      rs.seed(seeds[s]);
+      double* o = wind + s;   // element (i, c) at o[(i * 3 + c) * n]
+      double pu, pv, pw;      // previous knot's values
+      if (base) {             // environment.py:218-265
+        pu = base[0] + (0.0 + sigma[0] * rs.next_gauss());
+        pv = base[1] + (0.0 + sigma[0] * rs.next_gauss());
+        pw = base[2] + (0.0 + (sigma[0] * 0.3) * rs.next_gauss());
+        o[0] = pu; o[n] = pv; o[2 * n] = pw;
+        for (int32_t i = 1; i < k; ++i) {
+          const double* b0 = base + 3 * (i - 1);
+          const double* b1 = base + 3 * i;
+          const double tu = rho[i] * (pu - b0[0]) + (0.0 + innov[i] * rs.next_gauss());
+          const double tv = rho[i] * (pv - b0[1]) + (0.0 + innov[i] * rs.next_gauss());
+          const double tw = rho[i] * (pw - b0[2]) + (0.0 + (innov[i] * 0.3) * rs.next_gauss());
+          pu = b1[0] + tu; pv = b1[1] + tv; pw = b1[2] + tw;
+          o[(int64_t)(3 * i) * n] = pu; o[(int64_t)(3 * i + 1) * n] = pv; o[(int64_t)(3 * i + 2) * n] = pw;
+        }
+      } else {                // environment.py:125-200
+        const double cd = cdir[s], sd = sdir[s], sp = speed[s];
+        double m = sp * mean_scale[0];
+        pu = m * cd + (0.0 + sigma[0] * rs.next_gauss());
+        pv = m * sd + (0.0 + sigma[0] * rs.next_gauss());
+        pw = 0.0 + (sigma[0] * 0.3) * rs.next_gauss();
+        o[0] = pu; o[n] = pv; o[2 * n] = pw;
+        for (int32_t i = 1; i < k; ++i) {
+          const double m1 = sp * mean_scale[i];
+          const double tu = rho[i] * (pu - m * cd) + (0.0 + innov[i] * rs.next_gauss());
+          const double tv = rho[i] * (pv - m * sd) + (0.0 + innov[i] * rs.next_gauss());
+          const double tw = rho[i] * pw + (0.0 + (innov[i] * 0.3) * rs.next_gauss());
+          pu = m1 * cd + tu; pv = m1 * sd + tv; pw = tw;
+          m = m1;
+          o[(int64_t)(3 * i) * n] = pu; o[(int64_t)(3 * i + 1) * n] = pv; o[(int64_t)(3 * i + 2) * n] = pw;
+        }
+      }
+    }
+  });
   return ERPL_OK;
 }
 

@@ -309,6 +309,31 @@ def params_to_arrays(params_list):
     return a
 
 
+def legacy_wind_profiles(wind_model, alt, seeds, base=None, speed=None, cdir=None, sdir=None, threads=0):
+    """Wind tables [K, 3, n] of all samples, each from a fresh RandomState(seed): perturb_wind_profile
+    around `base` [K, 3] (environment.py:218-265), or generate_stochastic_profile with the power-law
+    mean wind of (speed, direction) per sample (environment.py:125-200); erpl_mc_legacy_wind_profiles."""
+    import ctypes as C
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+    n, K = seeds.size, len(alt)
+    sigma, rho, innov = wind_model._knot_constants(alt)
+    f = lambda v: np.ascontiguousarray(v, dtype=np.float64)
+    sigma, rho, innov = f(sigma), f([0.0] + list(rho[1:])), f([0.0] + list(innov[1:]))
+    ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    scale = None
+    if base is None:   # power law on scalars, as environment.py:118-123 evaluates it (`**` differs between scalar and array code)
+        scale = f([(np.float64(a) / 10.0) ** wind_model.power_law_exponent for a in alt])
+        speed, cdir, sdir = f(speed), f(cdir), f(sdir)
+    else:
+        base = f(base)
+    out = np.empty((K, 3, n), dtype=np.float64)
+    lib = _abi.load_library()
+    _abi.check(lib, lib.erpl_mc_legacy_wind_profiles(
+        ptr(seeds), C.c_int64(n), C.c_int32(K), ptr(sigma), ptr(rho), ptr(innov), ptr(base), ptr(scale),
+        ptr(speed), ptr(cdir), ptr(sdir), ptr(out), C.c_int32(threads)), "erpl_mc_legacy_wind_profiles")
+    return out
+
+
 def _ar1_profiles(wind_model, alt, g, mean_u=None, mean_v=None, base=None):
     """AR(1) turbulence of environment.py:161-198 / :242-263 for all samples: g [3K, n] holds each
     sample's normals in draw order (u, v, w per knot); returns [K, 3, n]."""
@@ -401,20 +426,19 @@ def dispersed_batch(rocket, motor, wind_model, base_initial_conditions, params_l
     b.motor[2] = mdot
     b.motor[3] = prop / mdot
 
-    # wind from another fresh RandomState(seed)
-    g = legacy_streams(seeds, "g" * (3 * len(alt)), by_output=True)
+    # wind from another fresh RandomState(seed): AR(1) turbulence in the C ABI (same operations, same
+    # order, fp64), the per-knot constants and the sample-wise offsets as NumPy expressions
     speed, direction = P["wind_speed"], P["wind_direction"]
     cd, sd = np.cos(direction), np.sin(direction)
     if use_base:
-        w = _ar1_profiles(wind_model, alt, g, base=np.asarray(base_wind_profile, dtype=np.float64))
+        w = legacy_wind_profiles(wind_model, alt, seeds, base=np.asarray(base_wind_profile, dtype=np.float64))
         w[:, 0, :] += speed * cd
         if planar:
             w[:, 1, :] = 0.0
         else:
             w[:, 1, :] += speed * sd
     else:
-        mean = [speed * ((np.float64(a) / 10.0) ** wind_model.power_law_exponent) for a in alt]   # environment.py:118-123
-        w = _ar1_profiles(wind_model, alt, g, mean_u=[m * cd for m in mean], mean_v=[m * sd for m in mean])
+        w = legacy_wind_profiles(wind_model, alt, seeds, speed=speed, cdir=cd, sdir=sd)
         if planar:
             w[:, 1, :] = 0.0
     b.wind = w

@@ -213,6 +213,20 @@ enum { ERPL_RS_GAUSS = 0, ERPL_RS_DOUBLE = 1 };
 int erpl_mc_legacy_random_streams(const uint32_t* seeds, int64_t n, const uint8_t* ops, int32_t m,
                                   double* out, int32_t by_output, int32_t threads);
 
+/* Host-side input preparation (no device work): the wind tables of all samples, each from a fresh
+ * RandomState(seeds[s]) with 3 normals per knot in the order u, v, w - AR(1) turbulence over the k
+ * altitude knots exactly as environment.py:218-265 (`base` != NULL: WindModel.perturb_wind_profile
+ * around the [k][3] baseline profile) or environment.py:125-200 (`base` == NULL:
+ * generate_stochastic_profile with the power-law mean wind (speed[s] * mean_scale[i]) * (cdir[s],
+ * sdir[s]), mean_scale[i] = (alt_i / 10)^exponent).  sigma / rho / innov are the per-knot turbulence
+ * sigma, AR(1) correlation and innovation sigma (rho[0], innov[0] unused).  Same operations in the
+ * same order as the reference, fp64, no contraction: bit-identical tables.  wind is [k][3][n] (the
+ * erpl_batch layout, host memory). */
+int erpl_mc_legacy_wind_profiles(const uint32_t* seeds, int64_t n, int32_t k, const double* sigma,
+                                 const double* rho, const double* innov, const double* base,
+                                 const double* mean_scale, const double* speed, const double* cdir,
+                                 const double* sdir, double* wind, int32_t threads);
+
 /* Raw device counters of the last run_batch (16 doubles): [0] queue head, [1] RK4 steps, [2] wave
  * iterations, [8..15] per-segment s_memtime sums of a -DERPL_STAMPS=1 diagnostic build (0 otherwise). */
 int erpl_mc_debug_counters(erpl_ctx* ctx, double* out16);

@@ -105,6 +105,20 @@ def test_vectorised_batch_equals_per_sample_loop(kind, base, planar):
     sub = flatten.dispersed_batch(*args, [pl_fast[i] for i in (5, 3, 77)], planar=planar, **kw)   # any subset / order
     assert np.array_equal(sub.wind, loop.wind[:, :, [5, 3, 77]]) and np.array_equal(sub.motor, loop.motor[:, [5, 3, 77]])
     assert flatten.dispersed_batch(*args, [], **kw).n == 0
+    # the C AR(1) synthesis against the same recursion written as NumPy array expressions
+    wm, seeds = models.WindModel(), np.arange(n, dtype=np.uint32)
+    P = flatten.generate_parameter_arrays(H.UNCERTAINTY, n)
+    if base == "csv":
+        g = flatten.legacy_streams(seeds, "g" * (3 * len(H.CSV_ALT)), by_output=True)
+        assert np.array_equal(flatten.legacy_wind_profiles(wm, H.CSV_ALT, seeds, base=H.CSV_WIND),
+                              flatten._ar1_profiles(wm, H.CSV_ALT, g, base=np.asarray(H.CSV_WIND, dtype=np.float64)))
+    else:
+        alt = np.linspace(0, 25000, 100)
+        g = flatten.legacy_streams(seeds, "g" * 300, by_output=True)
+        cd, sd = np.cos(P["wind_direction"]), np.sin(P["wind_direction"])
+        mean = [P["wind_speed"] * ((np.float64(a) / 10.0) ** wm.power_law_exponent) for a in alt]
+        assert np.array_equal(flatten.legacy_wind_profiles(wm, alt, seeds, speed=P["wind_speed"], cdir=cd, sdir=sd, threads=2),
+                              flatten._ar1_profiles(wm, alt, g, mean_u=[m * cd for m in mean], mean_v=[m * sd for m in mean]))
 
 
 def _mc_batch(kind, base, stream, ids):
