@@ -427,3 +427,60 @@ def test_full_size_batch_properties(engine, oracle):
     print(f"full-size fp32 subset: first-apogee match-rate@1e-3 {np.mean(e <= 1e-3):.3f}")
     assert np.mean(e <= 1e-3) >= 0.95
     assert np.array_equal(summ[_abi.SUM_RAIL_EXIT_TIME][pick], osum[_abi.SUM_RAIL_EXIT_TIME])
+
+
+# ------------------------------------------------------------------ configuration space
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_randomised_configurations(engine, oracle, seed):
+    """Rocket / motor / atmosphere / simulator attributes away from the reference's defaults: table
+    sizes up to the ABI limits, other time steps, rail lengths, parachute altitudes, damping, wind grids
+    with 2..1024 knots.  fp64 kernel vs oracle at the healthy-flight bar, fp32 at 0.1 %."""
+    rs = np.random.RandomState(seed)
+    kind = "solid" if seed % 2 else "liquid"
+    rocket, motor = models.Rocket(), H.make_motor(kind)
+    rocket.diameter *= rs.uniform(0.8, 1.3)
+    rocket.reference_area = np.pi * (rocket.diameter / 2) ** 2
+    rocket.reference_diameter = rocket.diameter
+    rocket.center_of_mass_dry = rs.uniform(4.6, 5.2)    # ahead of the CP: statically stable flights
+    rocket.fin_span *= rs.uniform(0.8, 1.4)
+    rocket.fin_sweep_angle = rs.uniform(0.0, 0.5)
+    rocket.parachute_deployment_altitude = rs.uniform(200.0, 3000.0)
+    rocket.parachute_cd = rs.uniform(0.8, 2.5)
+    rocket.power_off_drag_factor = rs.uniform(1.0, 1.5)
+    nm = int(rs.choice([2, 5, 11, _abi.MAX_MACH_KNOTS]))
+    mach = np.sort(np.concatenate([[0.0], rs.uniform(0.05, 6.0, nm - 1)]))
+    rocket.Cd_data = {"mach": list(mach), "cd0": list(rs.uniform(0.3, 0.7, nm)), "cda": list(rs.uniform(1.0, 1.5, nm))}
+    nc = int(rs.choice([2, 7, _abi.MAX_MACH_KNOTS]))
+    rocket.CP_shift_data = {"mach": list(np.sort(rs.uniform(0.0, 5.0, nc))), "cp_shift": list(rs.uniform(-0.1, 0.05, nc))}
+    rocket.cp_location = rocket._calculate_center_of_pressure()
+    if kind == "solid":
+        nt = int(rs.choice([3, 10, _abi.MAX_CURVE_KNOTS]))
+        motor.thrust_curve_time = np.concatenate([[0.0], np.sort(rs.uniform(0.1, 14.0, nt - 2)), [15.0]])
+        motor.thrust_curve_thrust = np.concatenate([[0.0], rs.uniform(4000.0, 16000.0, nt - 2), [0.0]])
+    atm = models.StandardAtmosphere()
+    atm.sea_level_temperature = rs.uniform(270.0, 305.0)
+    atm.sea_level_pressure = rs.uniform(95000.0, 104000.0)
+    cfg = flatten.config_from_objects(rocket, motor, atm, dt_initial=float(rs.choice([0.002, 0.01, 0.02])),
+                                      max_time=float(rs.choice([40.0, 120.0, 300.0])),
+                                      pitch_damping=rs.uniform(200.0, 2000.0), yaw_damping=rs.uniform(200.0, 2000.0))
+    cfg.rail_length = float(rs.choice([0.0, 3.0, 18.0]))
+    n = 96
+    pl = flatten.generate_parameter_samples(H.UNCERTAINTY, n)
+    k = int(rs.choice([2, 37, _abi.MAX_WIND_KNOTS]))
+    alt = np.sort(np.concatenate([[0.0], rs.uniform(10.0, 40000.0, k - 1)]))
+    basew = np.stack([rs.uniform(-8, 8, k), np.zeros(k), rs.uniform(-0.5, 0.5, k)], axis=1)
+    hb = flatten.dispersed_batch(rocket, motor, models.WindModel(), H.EXAMPLE_IC, pl, alt, basew, planar=True)
+    flags = _abi.FLAG_STOP_AT_APOGEE if seed % 3 else 0
+    osum, ostat = oracle.run_batch(cfg, hb, flags=flags)
+    summ, status = run_gpu(engine, cfg, hb, flags=flags)
+    assert np.mean((status & 0xFF) == (ostat & 0xFF)) >= 0.98
+    same = (status == ostat) & np.isfinite(osum[_abi.SUM_RANGE]) & (osum[_abi.SUM_RANGE] < 1e5)
+    assert same.sum() >= 0.7 * n
+    assert np.array_equal(summ[_abi.SUM_RAIL_EXIT_TIME], osum[_abi.SUM_RAIL_EXIT_TIME])
+    for row, tol in ((_abi.SUM_FIRST_APOGEE_ALT, 1e-8), (_abi.SUM_APOGEE_ALT, 1e-8), (_abi.SUM_MAX_SPEED, 1e-8)):
+        assert np.max(relerr(summ[row][same], osum[row][same])) < tol, (row, seed)
+    assert np.mean(summ[_abi.SUM_STEPS][same] == osum[_abi.SUM_STEPS][same]) >= 0.98
+    s32, t32 = run_gpu(engine, cfg, hb, prec=_abi.PREC_F32, flags=flags)
+    e = relerr(s32[_abi.SUM_FIRST_APOGEE_ALT][same], osum[_abi.SUM_FIRST_APOGEE_ALT][same])
+    print(f"config {seed} ({kind}, K={k}, mach knots {nm}/{nc}): healthy {same.sum()}/{n}, fp32 first-apogee max err {e.max():.2e}")
+    assert np.mean(e <= 1e-3) >= 0.97
