@@ -296,8 +296,10 @@ def main():
             },
         }
 
-    # ---------------- CPU baseline + parity (rank 0 only, outside the timed region) ----------------
-    if rank == 0 and (args.cpu_seconds > 0 or not args.no_parity):
+    # ---------------- CPU baseline + parity (N = 1 only, rank 0, outside the timed region) ----------------
+    if rank == 0 and world > 1:
+        out["cpu_baseline"] = None   # measured by the N = 1 run only (the host cores are shared by the ranks)
+    if rank == 0 and world == 1 and (args.cpu_seconds > 0 or not args.no_parity):
         from oracle import oracle as orc
         cores = host_cores()
         if args.cpu_seconds > 0:
