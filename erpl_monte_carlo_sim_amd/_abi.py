@@ -108,6 +108,13 @@ def load_library(path=None):
         raise ErplError(
             f"{p} not found: the HIP extension is not built. There is no CPU fallback; "
             "build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+    # PyTorch-ROCm ships its own copy of the HIP / HSA runtime.  Whichever copy a process maps first
+    # serves every later dlopen of that SONAME, and the device buffers torch allocates must come from
+    # the runtime that launches this library's kernels: load torch's first, always.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(p)
     lib.erpl_mc_abi_version.restype = C.c_int
     lib.erpl_mc_last_error.restype = C.c_char_p

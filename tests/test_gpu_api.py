@@ -139,3 +139,21 @@ def test_run_monte_carlo_device_large_n():
     assert 20000 < out["apogee_altitude"]["mean"] < 32000
     assert out["summary"].shape == (16, 20000) and out["status"].shape == (20000,)
     assert sum(out["termination_counts"].values()) == 20000
+
+
+def test_library_first_then_torch_in_a_fresh_process():
+    """The driver may call build() (which loads the library) and smoke() in one interpreter: loading the
+    C-ABI library before anything imported torch must still end up on ONE HIP runtime (torch's)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from erpl_monte_carlo_sim_amd import _abi, flatten\n"
+            "import numpy as np\n"
+            "assert flatten.legacy_streams(np.arange(4, dtype=np.uint32), 'gu').shape == (4, 2)\n"
+            "import torch\n"
+            "from erpl_monte_carlo_sim_amd.engine import TrajectoryEngine\n"
+            "eng = TrajectoryEngine(torch.device('cuda', 0)); eng.close(); print('ok')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
