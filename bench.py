@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--block", type=int, default=256)
     ap.add_argument("--max-blocks", type=int, default=0)
-    ap.add_argument("--refill", type=int, default=8)
+    ap.add_argument("--refill", type=int, default=1)
     ap.add_argument("--pipeline", type=int, default=2, help="depth of the extra pipelined measurement (1 = skip)")
     ap.add_argument("--chunk", type=int, default=-1, help="steps per launch between compactions (-1 = library default)")
     args = ap.parse_args()

@@ -211,7 +211,7 @@ struct erpl_ctx {
   int chunk = 0;
   int64_t cap = 0;
   unsigned long long* d_counters = nullptr;
-  int block = 256, max_blocks = 0, refill = 8;
+  int block = 256, max_blocks = 0, refill = 1;   // refill as soon as a lane is idle (measured best: 1..4)
   bool profiling = false;
   long long profiled_runs = 0;
   hipEvent_t ev[3 * ERPL_PROFILE_RING] = {};

@@ -90,7 +90,7 @@ class TrajectoryEngine:
         _abi.check(self.lib, self.lib.erpl_mc_set_config(self._ctx, C.byref(cfg)), "erpl_mc_set_config")
         self._cfg = cfg
 
-    def set_launch(self, block_threads=256, max_blocks=0, refill_threshold=8):
+    def set_launch(self, block_threads=256, max_blocks=0, refill_threshold=1):
         _abi.check(self.lib, self.lib.erpl_mc_set_launch(self._ctx, block_threads, max_blocks, refill_threshold),
                    "erpl_mc_set_launch")
 

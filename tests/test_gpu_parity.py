@@ -271,7 +271,7 @@ def test_launch_geometry_does_not_change_results(engine):
                     assert np.array_equal(status, base[prec][1]), (block, max_blocks, refill, chunk, prec)
                     assert np.array_equal(summ, base[prec][0], equal_nan=True), (block, max_blocks, refill, chunk, prec)
     finally:
-        engine.set_launch(256, 0, 8)
+        engine.set_launch(256, 0, 1)
         engine.set_chunk(0)
 
 
@@ -390,7 +390,7 @@ def test_full_size_batch_properties(engine, oracle):
         engine.set_chunk(700)
         s1, t1 = (x.clone() for x in engine.run(db))
     finally:
-        engine.set_launch(256, 0, 8)
+        engine.set_launch(256, 0, 1)
         engine.set_chunk(0)
     torch.cuda.synchronize()
     assert torch.equal(t0, t1)
