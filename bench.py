@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--refill", type=int, default=1)
     ap.add_argument("--pipeline", type=int, default=2, help="depth of the extra pipelined measurement (1 = skip)")
+    ap.add_argument("--waves", type=int, default=0, help="fp32 kernel build: 2 or 3 waves per SIMD (0 = library default, by batch size)")
     ap.add_argument("--chunk", type=int, default=-1, help="steps per launch between compactions (-1 = library default)")
     args = ap.parse_args()
 
@@ -130,6 +131,7 @@ def main():
     eng.set_launch(args.block, args.max_blocks, args.refill)
     if args.chunk >= 0:
         eng.set_chunk(args.chunk)
+    eng.set_waves_per_simd(args.waves)
     n = args.samples_per_gpu
     planar = args.workload.startswith("set_p")
     flags = _abi.FLAG_STOP_AT_APOGEE if args.workload == "set_p_apogee" else 0

@@ -89,7 +89,7 @@ EXPORTS = ("erpl_mc_abi_version", "erpl_mc_last_error", "erpl_mc_create", "erpl_
            "erpl_mc_set_config", "erpl_mc_reserve", "erpl_mc_run_batch", "erpl_mc_set_launch",
            "erpl_mc_last_stats", "erpl_mc_set_profiling", "erpl_mc_last_kernel_ms",
            "erpl_mc_kernel_ms_history", "erpl_mc_debug_counters", "erpl_mc_extract_histories", "erpl_mc_set_chunk",
-           "erpl_mc_legacy_random_streams", "erpl_mc_legacy_wind_profiles")
+           "erpl_mc_legacy_random_streams", "erpl_mc_legacy_wind_profiles", "erpl_mc_set_waves_per_simd")
 
 _lib = None
 
@@ -125,6 +125,7 @@ def load_library(path=None):
     lib.erpl_mc_run_batch.argtypes = [C.c_void_p, C.POINTER(ErplBatch), C.POINTER(ErplOut), C.c_void_p]
     lib.erpl_mc_set_launch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.erpl_mc_set_chunk.argtypes = [C.c_void_p, C.c_int]
+    lib.erpl_mc_set_waves_per_simd.argtypes = [C.c_void_p, C.c_int]
     lib.erpl_mc_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.erpl_mc_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.erpl_mc_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]

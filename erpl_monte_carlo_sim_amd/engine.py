@@ -94,6 +94,10 @@ class TrajectoryEngine:
         _abi.check(self.lib, self.lib.erpl_mc_set_launch(self._ctx, block_threads, max_blocks, refill_threshold),
                    "erpl_mc_set_launch")
 
+    def set_waves_per_simd(self, waves):
+        """fp32 flight-kernel build: 2 (256 VGPRs), 3 (168 VGPRs, three resident waves), 0 = by batch size."""
+        _abi.check(self.lib, self.lib.erpl_mc_set_waves_per_simd(self._ctx, int(waves)), "erpl_mc_set_waves_per_simd")
+
     def set_chunk(self, chunk_steps):
         """Step-chunked launches with per-GPU compaction in between (0 = single launch)."""
         _abi.check(self.lib, self.lib.erpl_mc_set_chunk(self._ctx, int(chunk_steps)), "erpl_mc_set_chunk")

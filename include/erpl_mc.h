@@ -180,6 +180,12 @@ int erpl_mc_run_batch(erpl_ctx* ctx, const erpl_batch* batch, const erpl_out* ou
  * persistent flight kernel (0 = library default), lane-refill threshold. */
 int erpl_mc_set_launch(erpl_ctx* ctx, int block_threads, int max_blocks, int refill_threshold);
 
+/* Which build of the fp32 flight kernel run_batch launches: 2 = all 256 VGPRs, two resident waves per
+ * SIMD; 3 = capped at 168 VGPRs (spills), three resident waves - faster once the batch is large enough
+ * to keep three waves per SIMD busy; 0 (default) = by batch size (3 from 2 304 samples per CU up).
+ * Results do not depend on the value (bitwise). */
+int erpl_mc_set_waves_per_simd(erpl_ctx* ctx, int waves);
+
 /* Per-GPU compaction (BASELINE config 5): integrate in launches of `chunk_steps` RK4 steps; lanes
  * that are still flying at the end of a chunk park their state densely in a resume queue and the
  * next launch continues them with fully populated waves.  0 = one launch, no compaction.  Results

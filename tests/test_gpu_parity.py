@@ -429,6 +429,32 @@ def test_full_size_batch_properties(engine, oracle):
     assert np.array_equal(summ[_abi.SUM_RAIL_EXIT_TIME][pick], osum[_abi.SUM_RAIL_EXIT_TIME])
 
 
+def test_two_and_three_wave_builds_agree_bitwise(engine):
+    """The fp32 flight kernel exists in a 256-VGPR build (two resident waves per SIMD) and a 168-VGPR
+    build (three, with spills), picked by batch size: same arithmetic, so identical bits - a sample's
+    result must not depend on the size of the batch it travels in."""
+    from erpl_monte_carlo_sim_amd import sampling
+    rocket, wm = models.Rocket(), models.WindModel()
+    try:
+        for kind, csv in (("liquid", False), ("solid", True)):
+            motor = H.make_motor(kind)
+            engine.set_config(H.make_config(kind))
+            db = sampling.synthetic_dispersions(20000, rocket, motor, wm, H.EXAMPLE_IC, engine.device,
+                                                precision=_abi.PREC_F32, seed=5, planar=csv,
+                                                base_altitude_profile=H.CSV_ALT if csv else None,
+                                                base_wind_profile=H.CSV_WIND if csv else None)
+            out = {}
+            for w in (2, 3):
+                engine.set_waves_per_simd(w)
+                s, t = engine.run(db)
+                out[w] = (s.clone(), t.clone())
+            torch.cuda.synchronize()
+            assert torch.equal(out[2][1], out[3][1]), kind
+            assert bool(((out[2][0] == out[3][0]) | (out[2][0].isnan() & out[3][0].isnan())).all()), kind
+    finally:
+        engine.set_waves_per_simd(0)
+
+
 # ------------------------------------------------------------------ configuration space
 @pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
 def test_randomised_configurations(engine, oracle, seed):

@@ -32,7 +32,7 @@ while time.time() - t0 < budget:
     flags = _abi.FLAG_STOP_AT_APOGEE if wl == "set_p_apogee" else 0
     block = int(rs.choice([64, 128, 256])); mb = int(rs.choice([0, 0, 1, 7, 300])); refill = int(rs.choice([1, 8, 40]))
     chunk = int(rs.choice([0, 0, 97, 1000, 5000]))
-    eng.set_launch(block, mb, refill); eng.set_chunk(chunk)
+    eng.set_launch(block, mb, refill); eng.set_chunk(chunk); eng.set_waves_per_simd(int(rs.choice([0, 2, 3])))
     s, t = eng.run(db, flags=flags)
     torch.cuda.synchronize()
     key = (n, kind, wl, prec)
