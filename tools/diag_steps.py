@@ -14,6 +14,7 @@ ap.add_argument("--planar", action="store_true")
 ap.add_argument("--apogee", action="store_true")
 ap.add_argument("--wind", default="syn", choices=["syn", "csv", "none"])
 ap.add_argument("--chunk", type=int, default=0)
+ap.add_argument("--waves", type=int, default=0)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 rocket, motor, atm, wm = models.Rocket(), models.LiquidMotor(), models.StandardAtmosphere(), models.WindModel()
@@ -25,6 +26,7 @@ if a.wind == "none":
     db.wind = None; db.alt_grid = None; db.k_wind = 0
 eng.set_profiling(True)
 eng.set_chunk(a.chunk)
+eng.set_waves_per_simd(a.waves)
 flags = _abi.FLAG_STOP_AT_APOGEE if a.apogee else 0
 for _ in range(2):
     s, st = eng.run(db, flags=flags)
