@@ -238,7 +238,7 @@ int erpl_mc_create(int device, erpl_ctx** out) {
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, 16 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_queue, 2 * (ERPL_MAX_PHASES + 2) * sizeof(unsigned long long));
   for (int i = 0; i < 3 * ERPL_PROFILE_RING && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
-  if (e != hipSuccess) { delete c; return fail(ERPL_ERR_HIP, "hipMalloc/hipEventCreate: %s", hipGetErrorString(e)); }
+  if (e != hipSuccess) { (void)erpl_mc_destroy(c); return fail(ERPL_ERR_HIP, "hipMalloc/hipEventCreate: %s", hipGetErrorString(e)); }
   *out = c;
   return ERPL_OK;
 }
@@ -260,6 +260,7 @@ int erpl_mc_set_config(erpl_ctx* c, const erpl_config* cfg) {
   int rc = build_tables(*cfg, T);
   if (rc != ERPL_OK) return rc;
   HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());   // a batch still in flight on some stream reads the tables being replaced
   HIP_TRY(hipMemcpy(c->d_tables, &T, sizeof(T), hipMemcpyHostToDevice));
   c->has_cfg = true;
   return ERPL_OK;
@@ -269,6 +270,7 @@ int erpl_mc_reserve(erpl_ctx* c, int64_t n) {
   if (!c || n < 0) return fail(ERPL_ERR_INVALID, "bad argument");
   if (n <= c->cap) return ERPL_OK;
   HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());   // the workspace being replaced may still be in use by a batch in flight
   for (int k = 0; k < 2; ++k) {
     (void)hipFree(c->res_r[k]); (void)hipFree(c->res_d[k]); (void)hipFree(c->res_i[k]);
     c->res_r[k] = nullptr; c->res_d[k] = nullptr; c->res_i[k] = nullptr;
