@@ -7,7 +7,7 @@ been built (run `python -c "import __graft_entry__ as g; g.build()"` or
 import ctypes as C
 import os
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 STATE_DIM = 14
 IC_DIM = 13
 ROCKET_DIM = 2
@@ -21,7 +21,10 @@ MAX_WIND_KNOTS = 1024
 PROFILE_RING = 256
 
 MOTOR_LIQUID, MOTOR_SOLID = 0, 1
-PREC_F64, PREC_F32 = 0, 1
+PREC_F64, PREC_F32, PREC_F64_FAST = 0, 1, 2
+PRECISIONS = {"f64": PREC_F64, "f32": PREC_F32, "f64_fast": PREC_F64_FAST}
+MAX_OVERLAP = 8
+DBG_ATMOSPHERE, DBG_AERO, DBG_RHS = 0, 1, 2
 FLAG_STOP_AT_APOGEE = 1
 
 # rows of the summary
@@ -89,7 +92,9 @@ EXPORTS = ("erpl_mc_abi_version", "erpl_mc_last_error", "erpl_mc_create", "erpl_
            "erpl_mc_set_config", "erpl_mc_reserve", "erpl_mc_run_batch", "erpl_mc_set_launch",
            "erpl_mc_last_stats", "erpl_mc_set_profiling", "erpl_mc_last_kernel_ms",
            "erpl_mc_kernel_ms_history", "erpl_mc_debug_counters", "erpl_mc_extract_histories", "erpl_mc_set_chunk",
-           "erpl_mc_legacy_random_streams", "erpl_mc_legacy_wind_profiles", "erpl_mc_set_waves_per_simd")
+           "erpl_mc_legacy_random_streams", "erpl_mc_legacy_wind_profiles", "erpl_mc_set_waves_per_simd",
+           "erpl_mc_set_overlap", "erpl_mc_submit_batch", "erpl_mc_wait_batch", "erpl_mc_synchronize",
+           "erpl_mc_debug_eval")
 
 _lib = None
 
@@ -124,6 +129,13 @@ def load_library(path=None):
     lib.erpl_mc_reserve.argtypes = [C.c_void_p, C.c_int64]
     lib.erpl_mc_run_batch.argtypes = [C.c_void_p, C.POINTER(ErplBatch), C.POINTER(ErplOut), C.c_void_p]
     lib.erpl_mc_set_launch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.erpl_mc_set_overlap.argtypes = [C.c_void_p, C.c_int]
+    lib.erpl_mc_submit_batch.argtypes = [C.c_void_p, C.POINTER(ErplBatch), C.POINTER(ErplOut), C.c_void_p,
+                                         C.POINTER(C.c_int64)]
+    lib.erpl_mc_wait_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    lib.erpl_mc_synchronize.argtypes = [C.c_void_p]
+    lib.erpl_mc_debug_eval.argtypes = [C.c_void_p, C.POINTER(ErplBatch), C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]
     lib.erpl_mc_set_chunk.argtypes = [C.c_void_p, C.c_int]
     lib.erpl_mc_set_waves_per_simd.argtypes = [C.c_void_p, C.c_int]
     lib.erpl_mc_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]

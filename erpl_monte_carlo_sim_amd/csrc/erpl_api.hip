@@ -198,25 +198,170 @@ int build_tables(const erpl_config& c, ErplTables& T) {
 
 }  // namespace
 
+// One workspace of the context: resume queues, queue cursors and counters of ONE batch in flight.
+// Slot 0 serves erpl_mc_run_batch (on the caller's stream); slots 0..depth-1 serve erpl_mc_submit_batch
+// round-robin, each on its own internal stream.  Whoever uses a slot first waits (on the device) for
+// the slot's previous batch and records `done` behind its own kernels.
+struct ErplSlot {
+  void* res_r[2] = {nullptr, nullptr};      // resume-queue records (see erpl_tables.h)
+  double* res_d[2] = {nullptr, nullptr};
+  int32_t* res_i[2] = {nullptr, nullptr};
+  unsigned long long* d_queue = nullptr;    // qcnt[ERPL_MAX_PHASES + 2] followed by qhead[...]
+  unsigned long long* d_counters = nullptr; // 16 words
+  int64_t cap = 0;
+  hipStream_t stream = nullptr;             // internal stream (created on first submit)
+  hipEvent_t in_ready = nullptr, done = nullptr;
+  bool used = false;                        // `done` has been recorded at least once
+  int64_t ticket = 0;                       // last batch submitted through this slot
+};
+
 struct erpl_ctx {
   int device = 0;
   int n_cu = 256;
   bool has_cfg = false;
   ErplTables h_tables;            // host copy (scalars are passed to the kernels by value)
   ErplTables* d_tables = nullptr;
-  void* res_r[2] = {nullptr, nullptr};      // resume-queue records (see erpl_tables.h)
-  double* res_d[2] = {nullptr, nullptr};
-  int32_t* res_i[2] = {nullptr, nullptr};
-  unsigned long long* d_queue = nullptr;    // qcnt[ERPL_MAX_PHASES + 2] followed by qhead[...]
+  ErplSlot slot[ERPL_MAX_OVERLAP];
+  int depth = 2;                  // slots erpl_mc_submit_batch cycles through
+  int64_t submitted = 0;          // tickets handed out
+  int last_slot = 0;              // slot of the most recent batch (erpl_mc_last_stats)
+  int64_t reserve_n = 0;          // erpl_mc_reserve request, applied to a slot when it is first used
   int chunk = 0;
   int waves = 0;   // 0 = choose by batch size
-  int64_t cap = 0;
-  unsigned long long* d_counters = nullptr;
   int block = 256, max_blocks = 0, refill = 1;   // refill as soon as a lane is idle (measured best: 1..4)
   bool profiling = false;
   long long profiled_runs = 0;
   hipEvent_t ev[3 * ERPL_PROFILE_RING] = {};
 };
+
+namespace {
+
+void slot_free_workspace(ErplSlot& s) {
+  for (int k = 0; k < 2; ++k) {
+    (void)hipFree(s.res_r[k]); (void)hipFree(s.res_d[k]); (void)hipFree(s.res_i[k]);
+    s.res_r[k] = nullptr; s.res_d[k] = nullptr; s.res_i[k] = nullptr;
+  }
+  s.cap = 0;
+}
+
+// Grows the slot's workspace to n samples.  The slot's previous batch may still be using the old one.
+int slot_reserve(ErplSlot& s, int64_t n) {
+  if (n <= s.cap) return ERPL_OK;
+  if (s.used) HIP_TRY(hipEventSynchronize(s.done));
+  slot_free_workspace(s);
+  for (int k = 0; k < 2; ++k) {
+    HIP_TRY(hipMalloc(&s.res_r[k], (size_t)n * ERPL_RES_R * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&s.res_d[k], (size_t)n * ERPL_RES_D * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&s.res_i[k], (size_t)n * ERPL_RES_I * sizeof(int32_t)));
+  }
+  s.cap = n;
+  return ERPL_OK;
+}
+
+int slot_init(ErplSlot& s) {
+  if (s.d_queue) return ERPL_OK;
+  HIP_TRY(hipMalloc((void**)&s.d_counters, 16 * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc((void**)&s.d_queue, 2 * (ERPL_MAX_PHASES + 2) * sizeof(unsigned long long)));
+  HIP_TRY(hipEventCreateWithFlags(&s.in_ready, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  return ERPL_OK;
+}
+
+void slot_destroy(ErplSlot& s) {
+  slot_free_workspace(s);
+  (void)hipFree(s.d_counters); (void)hipFree(s.d_queue);
+  if (s.in_ready) (void)hipEventDestroy(s.in_ready);
+  if (s.done) (void)hipEventDestroy(s.done);
+  if (s.stream) (void)hipStreamDestroy(s.stream);
+  s = ErplSlot();
+}
+
+int check_batch(const erpl_ctx* c, const erpl_batch* b, const erpl_out* o) {
+  if (!c || !b || !o) return fail(ERPL_ERR_INVALID, "NULL argument");
+  if (!c->has_cfg) return fail(ERPL_ERR_CONFIG, "erpl_mc_set_config has not been called");
+  if (b->n < 0) return fail(ERPL_ERR_INVALID, "negative batch size");
+  if (b->n == 0) return ERPL_OK;
+  if (b->n > 2147483647LL) return fail(ERPL_ERR_INVALID, "at most 2^31 - 1 samples per batch");
+  if (b->precision != ERPL_PREC_F64 && b->precision != ERPL_PREC_F32 && b->precision != ERPL_PREC_F64_FAST)
+    return fail(ERPL_ERR_INVALID, "unknown precision %d", b->precision);
+  if (b->k_wind < 0 || b->k_wind > ERPL_MAX_WIND_KNOTS)
+    return fail(ERPL_ERR_INVALID, "k_wind %d out of range 0..%d", b->k_wind, ERPL_MAX_WIND_KNOTS);
+  if (!b->ic || !b->rocket || !b->motor) return fail(ERPL_ERR_INVALID, "NULL input buffer");
+  if (b->k_wind > 0 && (!b->alt_grid || !b->wind)) return fail(ERPL_ERR_INVALID, "k_wind > 0 but no wind buffers");
+  if (!o->summary || !o->status) return fail(ERPL_ERR_INVALID, "NULL output buffer");
+  if (o->n_traj < 0 || (o->n_traj > 0 && (!o->traj_ids || !o->traj || !o->traj_len || o->traj_cap < 1 || o->traj_stride < 1)))
+    return fail(ERPL_ERR_INVALID, "inconsistent trajectory-capture arguments");
+  return ERPL_OK;
+}
+
+// Kernel arguments shared by every entry point that launches device code for a batch.
+void fill_common_args(const erpl_ctx* c, const erpl_batch* b, ErplKArgs& a) {
+  memset(&a, 0, sizeof(a));
+  a.n = b->n; a.k_wind = b->k_wind; a.flags = b->flags;
+  a.ic = b->ic; a.rocket = b->rocket; a.motor = b->motor; a.alt_grid = b->alt_grid; a.wind = b->wind;
+  a.tables = c->d_tables;
+  const ErplTables& T = c->h_tables;
+  a.n_union = T.n_union; a.n_curve = T.n_curve; a.motor_kind = T.motor_kind; a.n_coast = T.n_coast;
+  a.dt_rail = T.dt_rail; a.dt_flight = T.dt_flight; a.max_time = T.max_time;
+}
+
+// Rail + flight kernels of one batch through slot `si`, on stream `st`.
+int enqueue_batch(erpl_ctx* c, int si, const erpl_batch* b, const erpl_out* o, hipStream_t st) {
+  ErplSlot& s = c->slot[si];
+  int rc = slot_init(s);
+  if (rc != ERPL_OK) return rc;
+  rc = slot_reserve(s, (b->n > c->reserve_n) ? b->n : c->reserve_n);
+  if (rc != ERPL_OK) return rc;
+  // the slot's previous batch (possibly on another stream) must have drained its queues
+  if (s.used) HIP_TRY(hipStreamWaitEvent(st, s.done, 0));
+  HIP_TRY(hipMemsetAsync(s.d_counters, 0, 16 * sizeof(unsigned long long), st));
+  HIP_TRY(hipMemsetAsync(s.d_queue, 0, 2 * (ERPL_MAX_PHASES + 2) * sizeof(unsigned long long), st));
+  ErplKArgs a;
+  fill_common_args(c, b, a);
+  a.summary = o->summary; a.status = o->status;
+  for (int k = 0; k < 2; ++k) { a.res_r[k] = s.res_r[k]; a.res_d[k] = s.res_d[k]; a.res_i[k] = s.res_i[k]; }
+  a.res_cap = s.cap;
+  a.qcnt = s.d_queue; a.qhead = s.d_queue + (ERPL_MAX_PHASES + 2);
+  a.n_traj = o->n_traj; a.traj_stride = o->traj_stride; a.traj_cap = o->traj_cap;
+  a.traj_ids = o->traj_ids; a.traj = o->traj; a.traj_len = o->traj_len;
+  a.counters = s.d_counters;
+  a.refill_threshold = c->refill;
+  const ErplTables& T = c->h_tables;
+  const int max_blocks = c->max_blocks > 0 ? c->max_blocks : c->n_cu * 8;
+  // the three-wave build pays once the batch refills three resident waves per SIMD a few times over
+  // (measured +4..12 % from 3 rounds up; between 1 and 3 rounds the rounding of "rounds" decides)
+  a.waves_per_simd = c->waves ? c->waves : ((b->n >= (int64_t)c->n_cu * 4 * 64 * 3 * 3) ? 3 : 2);
+  // step-chunked launches with compaction in between (erpl_mc_set_chunk); every lane ends within
+  // ceil(max_time / dt) + 1 steps, so that many steps' worth of chunks drains the queue
+  int n_phases = 1;
+  a.chunk_steps = 0;
+  if (c->chunk > 0 && T.max_time > 0) {
+    const double max_steps = ceil(T.max_time / T.dt_flight) + 2.0;
+    double chunk = (double)c->chunk;
+    if (ceil(max_steps / chunk) + 1.0 > (double)ERPL_MAX_PHASES) chunk = ceil(max_steps / (double)(ERPL_MAX_PHASES - 2));
+    a.chunk_steps = (int)chunk;
+    n_phases = (int)ceil(max_steps / chunk) + 1;
+  }
+  void** ev = c->profiling ? (void**)&c->ev[3 * (c->profiled_runs % ERPL_PROFILE_RING)] : nullptr;
+  int lrc;
+  if (b->precision == ERPL_PREC_F64) lrc = erpl_launch_f64(a, &T.s64, c->block, max_blocks, n_phases, st, ev);
+  else if (b->precision == ERPL_PREC_F64_FAST) lrc = erpl_launch_f64f(a, &T.s64, c->block, max_blocks, n_phases, st, ev);
+  else lrc = erpl_launch_f32(a, &T.s32, c->block, max_blocks, n_phases, st, ev);
+  if (c->profiling && lrc == 0) c->profiled_runs++;
+  if (lrc != 0) return fail(ERPL_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  HIP_TRY(hipEventRecord(s.done, st));
+  s.used = true;
+  c->last_slot = si;
+  return ERPL_OK;
+}
+
+int wait_all_host(erpl_ctx* c) {
+  for (int i = 0; i < ERPL_MAX_OVERLAP; ++i)
+    if (c->slot[i].used) HIP_TRY(hipEventSynchronize(c->slot[i].done));
+  return ERPL_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -235,10 +380,9 @@ int erpl_mc_create(int device, erpl_ctx** out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
   hipError_t e = hipMalloc((void**)&c->d_tables, sizeof(ErplTables));
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, 16 * sizeof(unsigned long long));
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d_queue, 2 * (ERPL_MAX_PHASES + 2) * sizeof(unsigned long long));
   for (int i = 0; i < 3 * ERPL_PROFILE_RING && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
   if (e != hipSuccess) { (void)erpl_mc_destroy(c); return fail(ERPL_ERR_HIP, "hipMalloc/hipEventCreate: %s", hipGetErrorString(e)); }
+  if (slot_init(c->slot[0]) != ERPL_OK) { (void)erpl_mc_destroy(c); return ERPL_ERR_HIP; }
   *out = c;
   return ERPL_OK;
 }
@@ -246,8 +390,9 @@ int erpl_mc_create(int device, erpl_ctx** out) {
 int erpl_mc_destroy(erpl_ctx* c) {
   if (!c) return ERPL_OK;
   (void)hipSetDevice(c->device);
-  (void)hipFree(c->d_tables); (void)hipFree(c->d_counters); (void)hipFree(c->d_queue);
-  for (int k = 0; k < 2; ++k) { (void)hipFree(c->res_r[k]); (void)hipFree(c->res_d[k]); (void)hipFree(c->res_i[k]); }
+  (void)wait_all_host(c);
+  (void)hipFree(c->d_tables);
+  for (int i = 0; i < ERPL_MAX_OVERLAP; ++i) slot_destroy(c->slot[i]);
   for (int i = 0; i < 3 * ERPL_PROFILE_RING; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   delete c;
   return ERPL_OK;
@@ -255,12 +400,12 @@ int erpl_mc_destroy(erpl_ctx* c) {
 
 int erpl_mc_set_config(erpl_ctx* c, const erpl_config* cfg) {
   if (!c || !cfg) return fail(ERPL_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());   // a batch still in flight on some stream reads the tables being replaced
   ErplTables& T = c->h_tables;
   c->has_cfg = false;
   int rc = build_tables(*cfg, T);
   if (rc != ERPL_OK) return rc;
-  HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipDeviceSynchronize());   // a batch still in flight on some stream reads the tables being replaced
   HIP_TRY(hipMemcpy(c->d_tables, &T, sizeof(T), hipMemcpyHostToDevice));
   c->has_cfg = true;
   return ERPL_OK;
@@ -268,20 +413,16 @@ int erpl_mc_set_config(erpl_ctx* c, const erpl_config* cfg) {
 
 int erpl_mc_reserve(erpl_ctx* c, int64_t n) {
   if (!c || n < 0) return fail(ERPL_ERR_INVALID, "bad argument");
-  if (n <= c->cap) return ERPL_OK;
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipDeviceSynchronize());   // the workspace being replaced may still be in use by a batch in flight
-  for (int k = 0; k < 2; ++k) {
-    (void)hipFree(c->res_r[k]); (void)hipFree(c->res_d[k]); (void)hipFree(c->res_i[k]);
-    c->res_r[k] = nullptr; c->res_d[k] = nullptr; c->res_i[k] = nullptr;
+  if (n > c->reserve_n) c->reserve_n = n;
+  // slot 0 now (erpl_mc_run_batch stays allocation-free, hence graph-capturable); the overlap slots
+  // that have been used before grow too, fresh ones take the size on first use
+  for (int i = 0; i < ERPL_MAX_OVERLAP; ++i) {
+    if (i > 0 && !c->slot[i].d_queue) continue;
+    int rc = slot_init(c->slot[i]);
+    if (rc == ERPL_OK) rc = slot_reserve(c->slot[i], c->reserve_n);
+    if (rc != ERPL_OK) return rc;
   }
-  c->cap = 0;
-  for (int k = 0; k < 2; ++k) {
-    HIP_TRY(hipMalloc(&c->res_r[k], (size_t)n * ERPL_RES_R * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&c->res_d[k], (size_t)n * ERPL_RES_D * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&c->res_i[k], (size_t)n * ERPL_RES_I * sizeof(int32_t)));
-  }
-  c->cap = n;
   return ERPL_OK;
 }
 
@@ -310,65 +451,61 @@ int erpl_mc_set_launch(erpl_ctx* c, int block_threads, int max_blocks, int refil
 }
 
 int erpl_mc_run_batch(erpl_ctx* c, const erpl_batch* b, const erpl_out* o, void* stream) {
-  if (!c || !b || !o) return fail(ERPL_ERR_INVALID, "NULL argument");
-  if (!c->has_cfg) return fail(ERPL_ERR_CONFIG, "erpl_mc_set_config has not been called");
-  if (b->n < 0) return fail(ERPL_ERR_INVALID, "negative batch size");
-  if (b->n == 0) return ERPL_OK;
-  if (b->n > 2147483647LL) return fail(ERPL_ERR_INVALID, "at most 2^31 - 1 samples per batch");
-  if (b->precision != ERPL_PREC_F64 && b->precision != ERPL_PREC_F32)
-    return fail(ERPL_ERR_INVALID, "unknown precision %d", b->precision);
-  if (b->k_wind < 0 || b->k_wind > ERPL_MAX_WIND_KNOTS)
-    return fail(ERPL_ERR_INVALID, "k_wind %d out of range 0..%d", b->k_wind, ERPL_MAX_WIND_KNOTS);
-  if (!b->ic || !b->rocket || !b->motor) return fail(ERPL_ERR_INVALID, "NULL input buffer");
-  if (b->k_wind > 0 && (!b->alt_grid || !b->wind)) return fail(ERPL_ERR_INVALID, "k_wind > 0 but no wind buffers");
-  if (!o->summary || !o->status) return fail(ERPL_ERR_INVALID, "NULL output buffer");
-  if (o->n_traj < 0 || (o->n_traj > 0 && (!o->traj_ids || !o->traj || !o->traj_len || o->traj_cap < 1 || o->traj_stride < 1)))
-    return fail(ERPL_ERR_INVALID, "inconsistent trajectory-capture arguments");
+  int rc = check_batch(c, b, o);
+  if (rc != ERPL_OK || b->n == 0) return rc;
   HIP_TRY(hipSetDevice(c->device));
-  if (b->n > c->cap) {
-    int rc = erpl_mc_reserve(c, b->n);
-    if (rc != ERPL_OK) return rc;
-  }
-  hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), st));
-  ErplKArgs a;
-  memset(&a, 0, sizeof(a));
-  a.n = b->n; a.k_wind = b->k_wind; a.flags = b->flags;
-  a.ic = b->ic; a.rocket = b->rocket; a.motor = b->motor; a.alt_grid = b->alt_grid; a.wind = b->wind;
-  a.summary = o->summary; a.status = o->status;
-  for (int k = 0; k < 2; ++k) { a.res_r[k] = c->res_r[k]; a.res_d[k] = c->res_d[k]; a.res_i[k] = c->res_i[k]; }
-  a.res_cap = c->cap;
-  a.qcnt = c->d_queue; a.qhead = c->d_queue + (ERPL_MAX_PHASES + 2);
-  HIP_TRY(hipMemsetAsync(c->d_queue, 0, 2 * (ERPL_MAX_PHASES + 2) * sizeof(unsigned long long), st));
-  a.n_traj = o->n_traj; a.traj_stride = o->traj_stride; a.traj_cap = o->traj_cap;
-  a.traj_ids = o->traj_ids; a.traj = o->traj; a.traj_len = o->traj_len;
-  a.tables = c->d_tables;
-  a.counters = c->d_counters;
-  a.refill_threshold = c->refill;
-  const ErplTables& T = c->h_tables;
-  a.n_union = T.n_union; a.n_curve = T.n_curve; a.motor_kind = T.motor_kind; a.n_coast = T.n_coast;
-  a.dt_rail = T.dt_rail; a.dt_flight = T.dt_flight; a.max_time = T.max_time;
-  const int max_blocks = c->max_blocks > 0 ? c->max_blocks : c->n_cu * 8;
-  // the three-wave build pays once the batch refills three resident waves per SIMD a few times over
-  // (measured +4..12 % from 3 rounds up; between 1 and 3 rounds the rounding of "rounds" decides)
-  a.waves_per_simd = c->waves ? c->waves : ((b->n >= (int64_t)c->n_cu * 4 * 64 * 3 * 3) ? 3 : 2);
-  // step-chunked launches with compaction in between (erpl_mc_set_chunk); every lane ends within
-  // ceil(max_time / dt) + 1 steps, so that many steps' worth of chunks drains the queue
-  int n_phases = 1;
-  a.chunk_steps = 0;
-  if (c->chunk > 0 && T.max_time > 0) {
-    const double max_steps = ceil(T.max_time / T.dt_flight) + 2.0;
-    double chunk = (double)c->chunk;
-    if (ceil(max_steps / chunk) + 1.0 > (double)ERPL_MAX_PHASES) chunk = ceil(max_steps / (double)(ERPL_MAX_PHASES - 2));
-    a.chunk_steps = (int)chunk;
-    n_phases = (int)ceil(max_steps / chunk) + 1;
-  }
-  void** ev = c->profiling ? (void**)&c->ev[3 * (c->profiled_runs % ERPL_PROFILE_RING)] : nullptr;
-  int rc = (b->precision == ERPL_PREC_F64) ? erpl_launch_f64(a, &T.s64, c->block, max_blocks, n_phases, stream, ev)
-                                           : erpl_launch_f32(a, &T.s32, c->block, max_blocks, n_phases, stream, ev);
-  if (c->profiling && rc == 0) c->profiled_runs++;
-  if (rc != 0) return fail(ERPL_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return enqueue_batch(c, 0, b, o, (hipStream_t)stream);
+}
+
+int erpl_mc_set_overlap(erpl_ctx* c, int depth) {
+  if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
+  if (depth < 1 || depth > ERPL_MAX_OVERLAP) return fail(ERPL_ERR_INVALID, "overlap depth must be 1..%d", ERPL_MAX_OVERLAP);
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = wait_all_host(c);
+  if (rc != ERPL_OK) return rc;
+  c->depth = depth;
   return ERPL_OK;
+}
+
+int erpl_mc_submit_batch(erpl_ctx* c, const erpl_batch* b, const erpl_out* o, void* stream, int64_t* ticket) {
+  int rc = check_batch(c, b, o);
+  if (rc != ERPL_OK) return rc;
+  if (ticket) *ticket = c->submitted;   // an empty batch is complete as soon as its predecessors are
+  if (b->n == 0) return ERPL_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  const int si = (int)(c->submitted % c->depth);
+  ErplSlot& s = c->slot[si];
+  rc = slot_init(s);
+  if (rc != ERPL_OK) return rc;
+  if (!s.stream) HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+  // inputs written on the caller's stream so far are visible to the batch
+  HIP_TRY(hipEventRecord(s.in_ready, (hipStream_t)stream));
+  HIP_TRY(hipStreamWaitEvent(s.stream, s.in_ready, 0));
+  rc = enqueue_batch(c, si, b, o, s.stream);
+  if (rc != ERPL_OK) return rc;
+  s.ticket = ++c->submitted;
+  if (ticket) *ticket = s.ticket;
+  return ERPL_OK;
+}
+
+int erpl_mc_wait_batch(erpl_ctx* c, int64_t ticket, void* stream) {
+  if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
+  if (ticket > c->submitted) return fail(ERPL_ERR_INVALID, "ticket %lld has not been handed out", (long long)ticket);
+  HIP_TRY(hipSetDevice(c->device));
+  for (int i = 0; i < ERPL_MAX_OVERLAP; ++i) {
+    ErplSlot& s = c->slot[i];
+    if (!s.used || !s.stream) continue;
+    // a slot's stream runs its batches in order: the event of a later ticket covers the earlier ones
+    if (ticket < 0 || (s.ticket >= ticket && (s.ticket - ticket) % c->depth == 0))
+      HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, s.done, 0));
+  }
+  return ERPL_OK;
+}
+
+int erpl_mc_synchronize(erpl_ctx* c) {
+  if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
+  HIP_TRY(hipSetDevice(c->device));
+  return wait_all_host(c);
 }
 
 int erpl_mc_set_profiling(erpl_ctx* c, int enable) {
@@ -554,7 +691,8 @@ int erpl_mc_extract_histories(erpl_ctx* c, const erpl_batch* b, int64_t sample, 
                               double time_offset, double* out, void* stream) {
   if (!c || !b || !traj || !out) return fail(ERPL_ERR_INVALID, "NULL argument");
   if (!c->has_cfg) return fail(ERPL_ERR_CONFIG, "erpl_mc_set_config has not been called");
-  if (b->precision != ERPL_PREC_F64) return fail(ERPL_ERR_INVALID, "history extraction needs an ERPL_PREC_F64 batch");
+  if (b->precision != ERPL_PREC_F64 && b->precision != ERPL_PREC_F64_FAST)
+    return fail(ERPL_ERR_INVALID, "history extraction needs a batch with fp64 wind tables");
   if (sample < 0 || sample >= b->n || m < 0) return fail(ERPL_ERR_INVALID, "sample/m out of range");
   if (b->k_wind < 0 || b->k_wind > ERPL_MAX_WIND_KNOTS || (b->k_wind > 0 && (!b->alt_grid || !b->wind)))
     return fail(ERPL_ERR_INVALID, "bad wind arguments");
@@ -562,14 +700,30 @@ int erpl_mc_extract_histories(erpl_ctx* c, const erpl_batch* b, int64_t sample, 
   HIP_TRY(hipSetDevice(c->device));
   const ErplTables& T = c->h_tables;
   ErplKArgs a;
-  memset(&a, 0, sizeof(a));
-  a.n = b->n; a.k_wind = b->k_wind; a.flags = b->flags;
-  a.ic = b->ic; a.rocket = b->rocket; a.motor = b->motor; a.alt_grid = b->alt_grid; a.wind = b->wind;
+  fill_common_args(c, b, a);
   a.summary = out; a.traj = const_cast<double*>(traj); a.traj_cap = m; a.n_traj = sample;
-  a.tables = c->d_tables; a.counters = c->d_counters;
-  a.n_union = T.n_union; a.n_curve = T.n_curve; a.motor_kind = T.motor_kind; a.n_coast = T.n_coast;
-  a.dt_rail = T.dt_rail; a.dt_flight = T.dt_flight; a.max_time = T.max_time;
   int rc = erpl_launch_extract_f64(a, &T.s64, time_offset, stream);
+  if (rc != 0) return fail(ERPL_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return ERPL_OK;
+}
+
+int erpl_mc_debug_eval(erpl_ctx* c, const erpl_batch* b, int what, int64_t m, const double* in, double* out, void* stream) {
+  if (!c || !b || !in || !out) return fail(ERPL_ERR_INVALID, "NULL argument");
+  if (!c->has_cfg) return fail(ERPL_ERR_CONFIG, "erpl_mc_set_config has not been called");
+  if (what != ERPL_DBG_ATMOSPHERE && what != ERPL_DBG_AERO && what != ERPL_DBG_RHS) return fail(ERPL_ERR_INVALID, "unknown function %d", what);
+  if (b->n < 1 || m < 0 || !b->rocket || !b->motor) return fail(ERPL_ERR_INVALID, "need at least one sample with parameters");
+  if (b->k_wind < 0 || b->k_wind > ERPL_MAX_WIND_KNOTS || (b->k_wind > 0 && (!b->alt_grid || !b->wind)))
+    return fail(ERPL_ERR_INVALID, "bad wind arguments");
+  if (m == 0) return ERPL_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  const ErplTables& T = c->h_tables;
+  ErplKArgs a;
+  fill_common_args(c, b, a);
+  int rc;
+  if (b->precision == ERPL_PREC_F64) rc = erpl_launch_debug_f64(a, &T.s64, what, m, in, out, stream);
+  else if (b->precision == ERPL_PREC_F64_FAST) rc = erpl_launch_debug_f64f(a, &T.s64, what, m, in, out, stream);
+  else if (b->precision == ERPL_PREC_F32) rc = erpl_launch_debug_f32(a, &T.s32, what, m, in, out, stream);
+  else return fail(ERPL_ERR_INVALID, "unknown precision %d", b->precision);
   if (rc != 0) return fail(ERPL_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
   return ERPL_OK;
 }
@@ -578,7 +732,9 @@ int erpl_mc_debug_counters(erpl_ctx* c, double* out16) {
   if (!c || !out16) return fail(ERPL_ERR_INVALID, "NULL argument");
   unsigned long long h[16];
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+  const ErplSlot& ls = c->slot[c->last_slot];
+  if (ls.used) HIP_TRY(hipEventSynchronize(ls.done));
+  HIP_TRY(hipMemcpy(h, ls.d_counters, sizeof(h), hipMemcpyDeviceToHost));
   for (int i = 0; i < 16; ++i) out16[i] = (double)h[i];
   return ERPL_OK;
 }
@@ -587,7 +743,9 @@ int erpl_mc_last_stats(erpl_ctx* c, double* total_steps, double* wave_iterations
   if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
   unsigned long long h[4] = {0, 0, 0, 0};
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+  const ErplSlot& ls = c->slot[c->last_slot];
+  if (ls.used) HIP_TRY(hipEventSynchronize(ls.done));
+  HIP_TRY(hipMemcpy(h, ls.d_counters, sizeof(h), hipMemcpyDeviceToHost));
   if (total_steps) *total_steps = (double)h[1];
   if (wave_iterations) *wave_iterations = (double)h[2];
   return ERPL_OK;

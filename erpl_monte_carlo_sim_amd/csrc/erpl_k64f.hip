@@ -1,0 +1,17 @@
+// fp64 throughput instantiation (ERPL_PREC_F64_FAST): the short formulation of the fp32 RHS
+// (one reciprocal per denominator, interval-record atmosphere, no trig of atan2) carried in double
+// with FMA contraction.  MI355X runs fp64 vector FMAs at half the fp32 rate, so this build keeps
+// fp64 parity with the reference on the chaotic samples at a fraction of the cost
+// of the reference-order gate kernel (erpl_k64.hip).
+#define ERPL_REAL double
+#define ERPL_FAITHFUL 0
+#define ERPL_FAST_F32 0
+#define ERPL_FAST_F64 1
+#ifndef ERPL_STAGE_UNROLL
+#define ERPL_STAGE_UNROLL 4
+#endif
+#define ERPL_SUFFIX f64f
+#define ERPL_CAT_(a, b) a##b
+#define ERPL_CAT(a, b) ERPL_CAT_(a, b)
+#define ERPL_LAUNCH_NAME erpl_launch_f64f
+#include "erpl_kernels.inc"

@@ -120,6 +120,11 @@ extern "C++" {
 // n_phases flight launches follow the rail launch (1 when a.chunk_steps <= 0).
 int erpl_launch_f64(const ErplKArgs& a, const void* scalars, int block, int max_blocks, int n_phases, void* stream, void** ev);
 int erpl_launch_f32(const ErplKArgs& a, const void* scalars, int block, int max_blocks, int n_phases, void* stream, void** ev);
+int erpl_launch_f64f(const ErplKArgs& a, const void* scalars, int block, int max_blocks, int n_phases, void* stream, void** ev);
+// known-answer evaluation of one device function per lane (erpl_mc_debug_eval); in / out are [rows][m]
+int erpl_launch_debug_f64(const ErplKArgs& a, const void* scalars, int what, int64_t m, const double* in, double* out, void* stream);
+int erpl_launch_debug_f32(const ErplKArgs& a, const void* scalars, int what, int64_t m, const double* in, double* out, void* stream);
+int erpl_launch_debug_f64f(const ErplKArgs& a, const void* scalars, int what, int64_t m, const double* in, double* out, void* stream);
 // extraction of the per-step diagnostic histories (fp64 only): a.traj = records, a.traj_cap = m,
 // a.n_traj = sample index, a.summary = out [m][ERPL_DIAG_DIM]
 int erpl_launch_extract_f64(const ErplKArgs& a, const void* scalars, double time_offset, void* stream);

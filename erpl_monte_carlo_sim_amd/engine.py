@@ -47,7 +47,7 @@ class DeviceBatch:
             raise _abi.ErplError("dry_mass and propellant_mass must be positive")
         if not (np.all(hb.motor[2] > 0) and np.all(hb.motor[3] >= 0)):
             raise _abi.ErplError("mass_flow_rate must be positive and burn_time non-negative")
-        wdt = torch.float64 if precision == _abi.PREC_F64 else torch.float32
+        wdt = torch.float32 if precision == _abi.PREC_F32 else torch.float64
         f64 = dict(dtype=torch.float64, device=device)
         ic = torch.as_tensor(np.ascontiguousarray(hb.ic), **f64)
         rocket = torch.as_tensor(np.ascontiguousarray(hb.rocket), **f64)
@@ -63,8 +63,8 @@ class DeviceBatch:
 class TrajectoryEngine:
     """One engine (= one `erpl_ctx`) per GPU / torch.distributed rank."""
 
-    def __init__(self, device=None):
-        self.lib = _abi.load_library()
+    def __init__(self, device=None, lib_path=None):
+        self.lib = _abi.load_library(lib_path)   # lib_path: an experiment build (tools/), never the product
         if not torch.cuda.is_available():
             raise _abi.ErplError("no GPU visible to PyTorch-ROCm; this engine has no CPU fallback")
         if device is None:
@@ -110,8 +110,48 @@ class TrajectoryEngine:
         status = torch.empty((n,), dtype=torch.int32, device=self.device)
         return summary, status
 
+    def set_overlap(self, depth):
+        """Batches `submit()` keeps in flight at once (erpl_mc_set_overlap; 1..8, library default 2)."""
+        _abi.check(self.lib, self.lib.erpl_mc_set_overlap(self._ctx, int(depth)), "erpl_mc_set_overlap")
+
+    def submit(self, db, **kw):
+        """Like run(), but on one of the library's internal streams (erpl_mc_submit_batch): the batch
+        starts after everything enqueued on the current stream so far and may overlap earlier batches;
+        the current stream does NOT wait for it.  Call wait() before touching the outputs.  The ticket
+        of the batch is kept in `self.last_ticket`."""
+        return self.run(db, overlap=True, **kw)
+
+    def wait(self, ticket=-1, stream=None):
+        """Make `stream` (default: the current torch stream) wait on the device for a submitted batch
+        (ticket < 0: for all of them).  The host does not block."""
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        _abi.check(self.lib, self.lib.erpl_mc_wait_batch(self._ctx, int(ticket), C.c_void_p(st.cuda_stream)),
+                   "erpl_mc_wait_batch")
+
+    def synchronize(self):
+        _abi.check(self.lib, self.lib.erpl_mc_synchronize(self._ctx), "erpl_mc_synchronize")
+
+    def debug_eval(self, db, what, inputs):
+        """Device-side known-answer evaluation (erpl_mc_debug_eval): inputs [rows, m] -> outputs [rows', m]
+        float64, through the device functions of the kernel build `db.precision` selects."""
+        x = torch.as_tensor(np.ascontiguousarray(np.atleast_2d(inputs), dtype=np.float64), device=self.device)
+        m = int(x.shape[1])
+        rows = {_abi.DBG_ATMOSPHERE: 4, _abi.DBG_AERO: 5, _abi.DBG_RHS: 15}[what]
+        out = torch.full((rows, m), float("nan"), dtype=torch.float64, device=self.device)
+        b = _abi.ErplBatch()
+        b.n, b.precision, b.k_wind, b.flags = db.n, db.precision, db.k_wind, 0
+        b.ic, b.rocket, b.motor = db.ic.data_ptr(), db.rocket.data_ptr(), db.motor.data_ptr()
+        b.alt_grid = db.alt_grid.data_ptr() if db.k_wind else None
+        b.wind = db.wind.data_ptr() if db.k_wind else None
+        st = torch.cuda.current_stream(self.device)
+        rc = self.lib.erpl_mc_debug_eval(self._ctx, C.byref(b), int(what), m, C.c_void_p(x.data_ptr()),
+                                         C.c_void_p(out.data_ptr()), C.c_void_p(st.cuda_stream))
+        _abi.check(self.lib, rc, "erpl_mc_debug_eval")
+        torch.cuda.synchronize(self.device)
+        return out.cpu().numpy()
+
     def run(self, db, flags=0, summary=None, status=None, traj_ids=None, traj_stride=1, traj_cap=0,
-            stream=None):
+            stream=None, overlap=False):
         """Enqueue rail + flight kernels for the batch on the current torch stream.
         Returns (summary [16, n] f64, status [n] i32[, traj [m, cap, 15] f64, traj_len [m] i64]);
         asynchronous with respect to the host."""
@@ -133,8 +173,14 @@ class TrajectoryEngine:
             o.n_traj, o.traj_ids, o.traj_stride, o.traj_cap = len(ids), ids.data_ptr(), traj_stride, traj_cap
             o.traj, o.traj_len = traj.data_ptr(), tlen.data_ptr()
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
-        rc = self.lib.erpl_mc_run_batch(self._ctx, C.byref(b), C.byref(o), C.c_void_p(st.cuda_stream))
-        _abi.check(self.lib, rc, "erpl_mc_run_batch")
+        if overlap:
+            t = C.c_int64(0)
+            rc = self.lib.erpl_mc_submit_batch(self._ctx, C.byref(b), C.byref(o), C.c_void_p(st.cuda_stream), C.byref(t))
+            _abi.check(self.lib, rc, "erpl_mc_submit_batch")
+            self.last_ticket = t.value
+        else:
+            rc = self.lib.erpl_mc_run_batch(self._ctx, C.byref(b), C.byref(o), C.c_void_p(st.cuda_stream))
+            _abi.check(self.lib, rc, "erpl_mc_run_batch")
         if traj is not None:
             self._keep = ids
             return summary, status, traj, tlen

@@ -55,7 +55,7 @@ class MonteCarloAnalyzer:
     def _gpu_runner(self, n_traj_global, lo):
         eng = shared_engine(self.device)
         eng.set_config(self._config())
-        prec = _abi.PREC_F32 if self.precision == "f32" else _abi.PREC_F64
+        prec = _abi.PRECISIONS[self.precision]
         box = {}
 
         def runner(hb):
@@ -146,7 +146,7 @@ class MonteCarloAnalyzer:
         eng.set_config(self._config())
         rank, ws = dist.world()
         lo, hi, _ = dist.shard_bounds(n_samples, rank, ws)
-        prec = _abi.PREC_F32 if precision == "f32" else _abi.PREC_F64
+        prec = _abi.PRECISIONS[precision]
         t0 = time.time()
         db = sampling.synthetic_dispersions(max(hi - lo, 1), self.rocket, self.motor, self.wind_model,
                                             initial_conditions, eng.device, precision=prec, seed=seed + rank,

@@ -114,7 +114,7 @@ def synthetic_dispersions(n, rocket, motor, wind_model, base_initial_conditions,
     burn = prop / mdot
     mt = torch.stack([row0, ae, mdot, burn]).contiguous()
 
-    wdt = f64 if precision == _abi.PREC_F64 else torch.float32
+    wdt = torch.float32 if precision == _abi.PREC_F32 else f64
     use_base = base_wind_profile is not None and base_altitude_profile is not None
     if use_base:
         alt = torch.as_tensor(base_altitude_profile, dtype=f64, device=device)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ERPL_MC_ABI_VERSION 1
+#define ERPL_MC_ABI_VERSION 2
 
 #define ERPL_STATE_DIM 14   /* x y z vx vy vz q0(w) q1 q2 q3 wx wy wz propellant_fraction (simulator.py:130) */
 #define ERPL_IC_DIM 13      /* the same without propellant_fraction (always 1.0 at ignition, simulator.py:161) */
@@ -54,7 +54,15 @@ typedef enum erpl_status {
 } erpl_status;
 
 enum { ERPL_MOTOR_LIQUID = 0, ERPL_MOTOR_SOLID = 1 };
-enum { ERPL_PREC_F64 = 0, ERPL_PREC_F32 = 1 };
+/* erpl_batch.precision: which build of the kernels integrates the batch.
+ *   ERPL_PREC_F64       fp64 in the reference's operation order (IEEE division, libm-grade pow/exp/atan2/sin/cos,
+ *                       no FMA contraction): the correctness gate, tracks the CPU reference to ~1e-13 per call
+ *   ERPL_PREC_F64_FAST  fp64 arithmetic on the short formulation of the fp32 kernel (one reciprocal per
+ *                       denominator, interval-record atmosphere, FMA): keeps the reference's apogee on the
+ *                       chaotic samples too at several times the speed of the gate
+ *   ERPL_PREC_F32       fp32 state and RHS (time stays fp64): highest throughput; only the first-descent
+ *                       apogee of a diverging sample is within 0.1 % of the reference */
+enum { ERPL_PREC_F64 = 0, ERPL_PREC_F32 = 1, ERPL_PREC_F64_FAST = 2 };
 
 /* erpl_batch.flags */
 enum {
@@ -130,7 +138,7 @@ typedef struct erpl_config {
 /* One batch of independent samples (device pointers for erpl_mc_run_batch). */
 typedef struct erpl_batch {
   int64_t n;             /* samples */
-  int32_t precision;     /* ERPL_PREC_F64 (gate) | ERPL_PREC_F32 (throughput) */
+  int32_t precision;     /* ERPL_PREC_F64 (gate) | ERPL_PREC_F64_FAST | ERPL_PREC_F32 */
   int32_t k_wind;        /* wind knots; 0 = no profile -> zero wind (simulator.py:333-338) */
   int32_t flags;
   int32_t reserved;
@@ -139,7 +147,7 @@ typedef struct erpl_batch {
   const double* motor;   /* [4][n]   thrust (liquid: thrust_vacuum [N]; solid: curve multiplier),
                                      nozzle_exit_area, mass_flow_rate, burn_time */
   const double* alt_grid;/* [k_wind] shared altitude knots, strictly increasing */
-  const void* wind;      /* [k_wind][3][n] per-sample u,v,w; double if F64, float if F32 */
+  const void* wind;      /* [k_wind][3][n] per-sample u,v,w; float if F32, double otherwise */
 } erpl_batch;
 
 /* Outputs (device pointers).  traj_* are optional (NULL / 0 to disable): state history of a
@@ -160,8 +168,8 @@ typedef struct erpl_ctx erpl_ctx;
 int erpl_mc_abi_version(void);
 const char* erpl_mc_last_error(void);
 
-/* One context per GPU (one host thread / torch.distributed rank each).  Calls on one context are
- * serialised by the caller. */
+/* One context per GPU (one host thread / torch.distributed rank each).  HOST calls on one context are
+ * serialised by the caller; device work of successive batches is ordered by the library (below). */
 int erpl_mc_create(int device, erpl_ctx** out);
 int erpl_mc_destroy(erpl_ctx* ctx);
 
@@ -173,8 +181,26 @@ int erpl_mc_set_config(erpl_ctx* ctx, const erpl_config* cfg);
 int erpl_mc_reserve(erpl_ctx* ctx, int64_t n);
 
 /* Enqueues rail phase + flight integration + summaries for the batch on `hip_stream`
- * (a hipStream_t passed as void*; NULL = the default stream).  Asynchronous. */
+ * (a hipStream_t passed as void*; NULL = the default stream).  Asynchronous; stream-ordered: work
+ * enqueued on `hip_stream` afterwards sees the results.  A batch uses one of the context's
+ * workspaces; if that workspace is still in use by an earlier batch (on any stream), the new batch
+ * waits for it on the device, so two streams can never corrupt each other's queues. */
 int erpl_mc_run_batch(erpl_ctx* ctx, const erpl_batch* batch, const erpl_out* out, void* hip_stream);
+
+/* More than one batch in flight.  A single pass over a batch that just fills the GPU (BASELINE config 3:
+ * ~100 k samples) lasts as long as its longest trajectory while most lanes have already finished; the
+ * next batch can use those lanes.  erpl_mc_submit_batch enqueues the batch on one of `depth` internal
+ * streams, each with its own workspace (round-robin), AFTER everything enqueued on `hip_stream` so far
+ * (inputs written there are visible), and returns a ticket; it does NOT make `hip_stream` wait.
+ * erpl_mc_wait_batch makes `hip_stream` wait on the device for that batch (ticket < 0: for every batch
+ * submitted so far); the host never blocks.  Output buffers belong to the batch until then.  Results
+ * are bitwise those of erpl_mc_run_batch.  depth 1..8, default 2; changing it waits for work in flight. */
+#define ERPL_MAX_OVERLAP 8
+int erpl_mc_set_overlap(erpl_ctx* ctx, int depth);
+int erpl_mc_submit_batch(erpl_ctx* ctx, const erpl_batch* batch, const erpl_out* out, void* hip_stream, int64_t* ticket);
+int erpl_mc_wait_batch(erpl_ctx* ctx, int64_t ticket, void* hip_stream);
+/* Host-blocking wait for everything this context has enqueued. */
+int erpl_mc_synchronize(erpl_ctx* ctx);
 
 /* Launch geometry knobs (tuning / tests): threads per workgroup, max resident workgroups for the
  * persistent flight kernel (0 = library default), lane-refill threshold. */
@@ -232,6 +258,17 @@ int erpl_mc_legacy_wind_profiles(const uint32_t* seeds, int64_t n, int32_t k, co
                                  const double* rho, const double* innov, const double* base,
                                  const double* mean_scale, const double* speed, const double* cdir,
                                  const double* sdir, double* wind, int32_t threads);
+
+/* Known-answer evaluation ON THE DEVICE (tests): one function of the hot path per lane, through the
+ * device functions the flight kernel of `batch->precision` inlines.  Case j (0 <= j < m) uses the
+ * per-sample parameters and wind table of sample j % batch->n; in / out are device double arrays
+ * [rows][m].   what = ERPL_DBG_ATMOSPHERE: in altitude -> out T, P, rho, g (environment.py:26-108);
+ * ERPL_DBG_AERO: in mach, alpha, beta, propellant_fraction, power_on -> out cd, cl, cy, cm, cyaw
+ * (rocket.py:138-218; the fast builds take power_on = propellant_fraction > 0 as the RHS does);
+ * ERPL_DBG_RHS: in t, y[14], parachute latch -> out dy[14], latch (simulator.py:295-460). */
+enum { ERPL_DBG_ATMOSPHERE = 0, ERPL_DBG_AERO = 1, ERPL_DBG_RHS = 2 };
+int erpl_mc_debug_eval(erpl_ctx* ctx, const erpl_batch* batch, int what, int64_t m, const double* in, double* out,
+                       void* hip_stream);
 
 /* Raw device counters of the last run_batch (16 doubles): [0] queue head, [1] RK4 steps, [2] wave
  * iterations, [8..15] per-segment s_memtime sums of a -DERPL_STAMPS=1 diagnostic build (0 otherwise). */
