@@ -11,15 +11,27 @@ samples per GPU (x 8 GPUs = the 1 048 576 samples of configs[3]), LiquidMotor, r
 dispersion model (monte_carlo.py:156-179), synthetic 100-knot wind profile, full reference
 termination logic.  Weak scaling: every rank integrates its own 131 072-sample shard.
 
-Prints ONE JSON line (rank 0) with `roofline` and `cpu_baseline` objects:
-  roofline      dominant kernel = erpl_flight_f32; the path is vector-ALU bound, so
-                `achieved` = RK4 steps integrated per launch x 1570 algorithmic flops / the kernel's
-                HIP-event duration, against the 157.3 TFLOP/s fp32 vector peak; the HBM view that
-                north_star asks for is reported alongside (`hbm`).
+Passes are handed to the library with erpl_mc_submit_batch: up to `--overlap` of them are in flight
+on the library's internal streams (a pass over a batch that just fills the GPU lasts as long as its
+longest trajectory; the next pass uses the lanes that have already finished).  All K passes complete
+inside the timed region.
+
+Prints ONE JSON line (rank 0).  `value`, `dtype`, `apogee_match_rate`, `roofline` all describe the SAME
+kernel build (--precision, default f32) on the SAME shard:
+  apogee_match_rate  fraction of the shard's samples whose `apogee_altitude` (the reference's global
+                argmax, simulator.py:488-490) is within 0.1 % of the fp64 reference-order gate kernel
+                run on the same inputs (that kernel tracks the CPU oracle on 100 % of the cfg-2 set:
+                `parity.cfg2_set_r_1k`); first-descent apogee, end reasons and a breakdown by class
+                of the reference outcome are under `parity`.
+  roofline      dominant kernel = erpl_flight_<dtype>; the path is vector-ALU bound:
+                `achieved` = RK4 steps integrated per launch x 1570 algorithmic flops / the GPU time per
+                launch (HIP events on the stream around the timed region / K); the per-dispatch
+                duration the library's own events (and rocprofv3) see is reported beside it - with
+                `overlap` launches in flight a dispatch lasts about `overlap` times the time per launch.
   cpu_baseline  the CPU oracle (C fp64 restatement, OpenMP over samples, all host cores) on a
-                bounded sample of the same shard; it is a reported baseline, not the target.
-  parity        apogee-match rates of the GPU results against that oracle (fp32 shard sample)
-                and of the fp64 gate on 1 k reference-faithful samples (BASELINE configs[1]).
+                bounded sample of the same shard; a reported baseline, not the target.
+  f64_fast      the same K passes with the ERPL_PREC_F64_FAST build (fp64 arithmetic, short
+                formulation): its own value / apogee_match_rate / roofline triple.
 """
 import argparse
 import json
@@ -36,8 +48,8 @@ sys.path.insert(0, ROOT)
 from erpl_monte_carlo_sim_amd import _abi, flatten, models, sampling  # noqa: E402
 from erpl_monte_carlo_sim_amd.engine import DeviceBatch, TrajectoryEngine  # noqa: E402
 
-FLOPS_PER_STEP = 1570.0        # SURVEY.md §8d algorithmic count (4 RHS x 343 + ~200)
-PEAK_FP32_VECTOR_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table
+FLOPS_PER_STEP = 1570.0          # SURVEY.md 8d algorithmic count (4 RHS x 343 + ~200)
+PEAK_TFLOPS = {"f32": 157.3, "f64": 78.65, "f64_fast": 78.65}   # MI355X_MICROARCH.md vector peaks
 PEAK_HBM_GBPS = 8000.0
 
 EXAMPLE_IC = {"position": [0.0, 0.0, 10.0], "velocity": [0, 0, 0.0],
@@ -66,9 +78,42 @@ def host_cores():
 
 def relerr(a, b):
     same = (a == b) | (np.isnan(a) & np.isnan(b))
-    with np.errstate(invalid="ignore", divide="ignore"):
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
         e = np.abs(a - b) / np.abs(b)
-    return np.where(same, 0.0, e)
+    return np.where(same, 0.0, np.where(np.isnan(e), np.inf, e))
+
+
+def match_report(ref_s, ref_t, got_s, got_t):
+    """Match rates of (got) against (ref) at the north-star 0.1 % bar, overall and by class of the
+    REFERENCE outcome: apogee reached before the first descent (the flight never topped it afterwards),
+    apogee set after the first descent (tumble / blow-up), altitude turned NaN."""
+    e_ap = relerr(got_s[_abi.SUM_APOGEE_ALT], ref_s[_abi.SUM_APOGEE_ALT])
+    e_fa = relerr(got_s[_abi.SUM_FIRST_APOGEE_ALT], ref_s[_abi.SUM_FIRST_APOGEE_ALT])
+    same_end = (got_t & 0xFF) == (ref_t & 0xFF)
+    out = {"n": int(ref_s.shape[1]),
+           "apogee_match_rate_0p1pct": float(np.mean(e_ap <= 1e-3)),
+           "first_apogee_match_rate_0p1pct": float(np.mean(e_fa <= 1e-3)),
+           "same_end_reason": float(np.mean(same_end)), "by_reference_class": {}}
+    nan = (ref_t & _abi.ST_NAN) != 0
+    calm = (~nan) & (ref_s[_abi.SUM_APOGEE_ALT] == ref_s[_abi.SUM_FIRST_APOGEE_ALT])
+    for name, m in (("apogee_before_first_descent", calm), ("apogee_after_first_descent", (~nan) & ~calm),
+                    ("altitude_turned_nan", nan)):
+        if m.any():
+            out["by_reference_class"][name] = {"fraction": float(np.mean(m)),
+                                               "apogee_match_rate": float(np.mean(e_ap[m] <= 1e-3)),
+                                               "first_apogee_match_rate": float(np.mean(e_fa[m] <= 1e-3)),
+                                               "same_end_reason": float(np.mean(same_end[m]))}
+    return out
+
+
+def as_precision(db, prec):
+    """The SAME samples for another kernel build (fp64 draws; the wind table rounded for fp32)."""
+    wind = db.wind
+    if prec == _abi.PREC_F32 and wind.dtype != torch.float32:
+        wind = wind.float().contiguous()
+    elif prec != _abi.PREC_F32 and wind.dtype != torch.float64:
+        raise SystemExit("cannot widen an fp32 wind table")
+    return DeviceBatch(db.ic, db.rocket, db.motor, db.alt_grid, wind, prec)
 
 
 def host_slice(db, m):
@@ -85,19 +130,20 @@ def host_slice(db, m):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples-per-gpu", type=int, default=131072)
     ap.add_argument("--workload", default="set_s", choices=["set_s", "set_p_apogee", "set_p_full", "csv_chute"])
     ap.add_argument("--motor", default="liquid", choices=["liquid", "solid"])
-    ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--precision", default="f32", choices=["f32", "f64", "f64_fast"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--block", type=int, default=256)
+    ap.add_argument("--no-second-leg", action="store_true", help="skip the f64_fast leg")
+    ap.add_argument("--block", type=int, default=0, help="threads per workgroup (0 = library default)")
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--refill", type=int, default=1)
-    ap.add_argument("--pipeline", type=int, default=2, help="depth of the extra pipelined measurement (1 = skip)")
-    ap.add_argument("--waves", type=int, default=0, help="fp32 kernel build: 2 or 3 waves per SIMD (0 = library default, by batch size)")
+    ap.add_argument("--overlap", type=int, default=-1, help="passes in flight (erpl_mc_set_overlap); 0 = erpl_mc_run_batch on the stream; -1 = library default")
+    ap.add_argument("--waves", type=int, default=0, help="fp32 kernel build: 2 or 3 waves per SIMD (0 = library default)")
     ap.add_argument("--chunk", type=int, default=-1, help="steps per launch between compactions (-1 = library default)")
     args = ap.parse_args()
 
@@ -112,11 +158,13 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
+    gloo_rehearsal = False
     if world > 1:
         import torch.distributed as dist
         # "nccl" is RCCL on ROCm.  ERPL_BENCH_BACKEND=gloo exists only to rehearse the N > 1 code path on
         # a box with a single GPU (RCCL refuses two ranks on one device); it is never used for numbers.
         backend = os.environ.get("ERPL_BENCH_BACKEND", "nccl")
+        gloo_rehearsal = backend != "nccl"
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -125,182 +173,209 @@ def main():
     rocket, atm, wm = models.Rocket(), models.StandardAtmosphere(), models.WindModel()
     motor = models.SolidMotor() if args.motor == "solid" else models.LiquidMotor()
     cfg = flatten.config_from_objects(rocket, motor, atm)
-    prec = _abi.PREC_F32 if args.precision == "f32" else _abi.PREC_F64
     eng = TrajectoryEngine(device)
     eng.set_config(cfg)
-    eng.set_launch(args.block, args.max_blocks, args.refill)
+    if args.block > 0 or args.max_blocks > 0 or args.refill != 1:
+        eng.set_launch(args.block if args.block > 0 else 64, args.max_blocks, args.refill)
     if args.chunk >= 0:
         eng.set_chunk(args.chunk)
     eng.set_waves_per_simd(args.waves)
+    if args.overlap > 0:
+        eng.set_overlap(args.overlap)
+    depth = args.overlap if args.overlap >= 0 else 3
     n = args.samples_per_gpu
     planar = args.workload.startswith("set_p")
     flags = _abi.FLAG_STOP_AT_APOGEE if args.workload == "set_p_apogee" else 0
     csv = args.workload == "csv_chute"
-    db = sampling.synthetic_dispersions(
-        n, rocket, motor, wm, EXAMPLE_IC, device, precision=prec, seed=1234 + rank, planar=planar or csv,
-        base_altitude_profile=CSV_ALT if csv else None, base_wind_profile=CSV_WIND if csv else None)
+    # one set of samples for every kernel build: fp64 draws, the wind table rounded once for fp32
+    db64 = sampling.synthetic_dispersions(
+        n, rocket, motor, wm, EXAMPLE_IC, device, precision=_abi.PREC_F64, seed=1234 + rank, planar=planar or csv,
+        base_altitude_profile=CSV_ALT if csv else None, base_wind_profile=CSV_WIND if csv else None, engine=eng)
     eng.reserve(n)
-    gloo_rehearsal = world > 1 and os.environ.get("ERPL_BENCH_BACKEND", "nccl") != "nccl"
-    # N > 1: the all-gather of pass i (RCCL over xGMI, on RCCL's own stream) overlaps the kernels of pass
-    # i+1, so outputs and gather buffers are double-buffered; every gather issued inside the timed region
-    # is waited for before the closing barrier.
-    nbuf = 2 if world > 1 else 1
-    outs = [eng.alloc_outputs(n) for _ in range(nbuf)]
-    gath = []
-    for _ in range(nbuf if world > 1 else 0):
-        gdev = "cpu" if gloo_rehearsal else device
-        gath.append((torch.empty((world * _abi.SUMMARY_DIM, n), dtype=torch.float64, device=gdev),
-                     torch.empty((world * n,), dtype=torch.int32, device=gdev)))
-    pending = [None] * nbuf
+    side = torch.cuda.Stream(device) if world > 1 else None
 
-    def wait_gather(k):
-        if pending[k] is not None:
-            for w in pending[k]:
-                w.wait()
-            pending[k] = None
+    def timed_leg(precision):
+        """W warm-up + K timed passes of one kernel build; returns the measurements of this rank."""
+        prec = _abi.PRECISIONS[precision]
+        db = as_precision(db64, prec)
+        nbuf = max(depth, 1) + (1 if world > 1 else 0)
+        outs = [eng.alloc_outputs(n) for _ in range(nbuf)]
+        gath = []
+        for _ in range(nbuf if world > 1 else 0):
+            gdev = "cpu" if gloo_rehearsal else device
+            gath.append((torch.empty((world * _abi.SUMMARY_DIM, n), dtype=torch.float64, device=gdev),
+                         torch.empty((world * n,), dtype=torch.int32, device=gdev)))
+        pending = [None] * nbuf
 
-    def step(i):
-        k = i % nbuf
-        wait_gather(k)  # the gather that last read these output buffers
-        s_k, t_k = outs[k]
-        eng.run(db, flags=flags, summary=s_k, status=t_k)
-        if world > 1:  # all-gather of the per-sample summaries (monte_carlo.py:76-83)
-            g_s, g_t = gath[k]
-            if gloo_rehearsal:
-                torch.cuda.synchronize()
-                s_k, t_k = s_k.cpu(), t_k.cpu()
-            pending[k] = [dist.all_gather_into_tensor(g_s, s_k, async_op=True),
-                          dist.all_gather_into_tensor(g_t, t_k, async_op=True)]
+        def wait_gather(k):
+            if pending[k] is not None:
+                for w in pending[k]:
+                    w.wait()
+                pending[k] = None
 
-    def drain():
-        for k in range(nbuf):
-            wait_gather(k)
+        def step(i):
+            k = i % nbuf
+            wait_gather(k)  # the gather that last read these output buffers
+            s_k, t_k = outs[k]
+            if depth > 0:
+                eng.submit(db, flags=flags, summary=s_k, status=t_k)
+            else:
+                eng.run(db, flags=flags, summary=s_k, status=t_k)
+            if world > 1:
+                # all-gather of the per-sample summaries (monte_carlo.py:76-83) on a side stream that waits
+                # for THIS pass only: RCCL over xGMI overlaps the kernels of the following passes
+                g_s, g_t = gath[k]
+                with torch.cuda.stream(side):
+                    if depth > 0:
+                        eng.wait(eng.last_ticket, side)
+                    else:
+                        side.wait_stream(torch.cuda.current_stream(device))
+                    if gloo_rehearsal:
+                        side.synchronize()
+                        s_k, t_k = s_k.cpu(), t_k.cpu()
+                    pending[k] = [dist.all_gather_into_tensor(g_s, s_k, async_op=True),
+                                  dist.all_gather_into_tensor(g_t, t_k, async_op=True)]
 
-    eng.set_profiling(True)
-    for i in range(args.warmup):
-        step(i)
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo_rehearsal else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    summary, status = outs[(args.steps - 1) % nbuf]
-    if world > 1:  # every rank must hold every rank's summaries: rank-major rows, own block == own results
-        g_s, g_t = gath[(args.steps - 1) % nbuf]
-        own = g_s[rank * _abi.SUMMARY_DIM:(rank + 1) * _abi.SUMMARY_DIM].to(summary.device)
-        if not bool(((own == summary) | (own.isnan() & summary.isnan())).all()) or \
-                not torch.equal(g_t[rank * n:(rank + 1) * n].to(status.device), status):
-            raise SystemExit("all-gather result does not contain this rank's summaries")
+        def drain():
+            if depth > 0:
+                eng.wait()          # the current stream waits for every pass in flight
+            for k in range(nbuf):
+                wait_gather(k)
 
-    rail_ms, flight_ms = eng.kernel_ms_history(args.steps)
-    phys_steps, wave_iters = eng.last_stats()
-    st = status.cpu().numpy()
-    sm = summary.cpu().numpy()
-    steps_col = sm[_abi.SUM_STEPS]
-    # ---- extra (N = 1 only, never `value`): the same K passes software-pipelined two deep on two
-    # streams / two contexts / two output buffers.  A single pass is bound by the sequential latency of
-    # its longest trajectory; independent passes overlap each other's sparse tails. ----
-    pipelined = None
-    if world == 1 and args.pipeline > 1:
-        engs = [eng] + [TrajectoryEngine(device) for _ in range(args.pipeline - 1)]
-        pouts = [(summary, status)] + [eng.alloc_outputs(n) for _ in range(args.pipeline - 1)]
-        streams = [torch.cuda.Stream(device) for _ in range(args.pipeline)]
-        for e in engs[1:]:
-            e.set_config(cfg); e.set_launch(args.block, args.max_blocks, args.refill); e.reserve(n)
-            if args.chunk >= 0:
-                e.set_chunk(args.chunk)
-        for k in range(args.pipeline):       # warm-up of the extra contexts
-            with torch.cuda.stream(streams[k]):
-                engs[k].run(db, flags=flags, summary=pouts[k][0], status=pouts[k][1], stream=streams[k])
+        eng.set_profiling(True)
+        for i in range(args.warmup):
+            step(i)
+        drain()
         torch.cuda.synchronize()
-        tp = time.perf_counter()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
         for i in range(args.steps):
-            k = i % args.pipeline
-            engs[k].run(db, flags=flags, summary=pouts[k][0], status=pouts[k][1], stream=streams[k])
+            step(i)
+        drain()
+        ev1.record()
         torch.cuda.synchronize()
-        el_p = time.perf_counter() - tp
-        pipelined = {"depth": args.pipeline, "value": n * args.steps / el_p, "unit": "trajectories/s",
-                     "ms_per_step": el_p / args.steps * 1e3,
-                     "note": "independent passes overlapped on separate streams/contexts; not the headline"}
-        for e in engs[1:]:
-            e.close()
-
-    if world > 1:
-        tot = torch.tensor([phys_steps], dtype=torch.float64, device="cpu" if gloo_rehearsal else device)
-        dist.all_reduce(tot)
-        phys_total = float(tot.item())
-    else:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        gpu_ms = ev0.elapsed_time(ev1)
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo_rehearsal else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        last = (args.steps - 1) % nbuf
+        summary, status = outs[last]
+        if world > 1:  # every rank must hold every rank's summaries: rank-major rows, own block == own results
+            g_s, g_t = gath[last]
+            own = g_s[rank * _abi.SUMMARY_DIM:(rank + 1) * _abi.SUMMARY_DIM].to(summary.device)
+            if not bool(((own == summary) | (own.isnan() & summary.isnan())).all()) or \
+                    not torch.equal(g_t[rank * n:(rank + 1) * n].to(status.device), status):
+                raise SystemExit("all-gather result does not contain this rank's summaries")
+        rail_ms, flight_ms = eng.kernel_ms_history(args.steps)
+        phys_steps, wave_iters = eng.last_stats()
         phys_total = phys_steps
+        if world > 1:
+            tot = torch.tensor([phys_steps], dtype=torch.float64, device="cpu" if gloo_rehearsal else device)
+            dist.all_reduce(tot)
+            phys_total = float(tot.item())
+        return {"precision": precision, "prec": prec, "db": db, "elapsed": elapsed, "gpu_ms": gpu_ms,
+                "summary": summary, "status": status, "rail_ms": rail_ms, "flight_ms": flight_ms,
+                "phys_steps": phys_steps, "wave_iters": wave_iters, "phys_total": phys_total}
 
-    out = None
-    if rank == 0:
+    def leg_json(L):
+        """The value / roofline part of the JSON line for one leg (rank 0)."""
+        precision = L["precision"]
         total_traj = n * world
-        value = total_traj * args.steps / elapsed
-        fl = float(np.mean(flight_ms))
-        rl = float(np.mean(rail_ms))
-        achieved_tf = phys_steps * FLOPS_PER_STEP / (fl * 1e-3) / 1e12
-        es = 4 if prec == _abi.PREC_F32 else 8
-        algo_bytes = (db.input_bytes() + 2 * n * (14 * es + 8 + 4) + n * (_abi.SUMMARY_DIM * 8 + 4))
-        hbm_gbps = algo_bytes / ((fl + rl) * 1e-3) / 1e9
+        value = total_traj * args.steps / L["elapsed"]
+        fl, rl = float(np.mean(L["flight_ms"])), float(np.mean(L["rail_ms"]))
+        per_launch_ms = L["gpu_ms"] / args.steps     # GPU time per launch over the timed region (HIP events)
+        peak = PEAK_TFLOPS[precision]
+        achieved_tf = L["phys_steps"] * FLOPS_PER_STEP / (per_launch_ms * 1e-3) / 1e12
+        dispatch_tf = L["phys_steps"] * FLOPS_PER_STEP / (fl * 1e-3) / 1e12
+        es = 4 if L["prec"] == _abi.PREC_F32 else 8
+        algo_bytes = (L["db"].input_bytes() + 2 * n * (14 * es + 8 + 4) + n * (_abi.SUMMARY_DIM * 8 + 4))
+        hbm_gbps = algo_bytes / (per_launch_ms * 1e-3) / 1e9
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
         # (FETCH_SIZE / WRITE_SIZE need the profiler, they cannot be read from inside this process)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")
-        if os.path.exists(tpath) and args.workload == "set_s" and n == 131072 and args.precision == "f32":
-            traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
-        out = {
-            "metric": "Monte Carlo trajectories/sec (whole node) + apogee-match rate",
-            "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.precision, "data": "synthetic",
-            "config": {
-                "workload": f"{args.workload}: {n} dispersed 6-DOF samples/GPU ({total_traj} total), "
-                            f"{args.motor} motor, reference dispersion model, "
-                            f"{'CSV base wind K=6' if csv else 'synthetic wind K=100'}, "
-                            f"rail dt=0.01 + RK4 dt=0.005, "
-                            f"{'to first-descent apogee' if flags else 'full reference termination logic'}",
-                "samples_per_gpu": n, "precision": args.precision,
-                "parallelism": f"sample-shard x{world}" + (" + RCCL all-gather of [16,n] summaries overlapped with the next pass" if world > 1 else ""),
-            },
-            "trajectory_steps_per_s": phys_total * args.steps / elapsed,
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")
+        if os.path.exists(tpath) and args.workload == "set_s" and n == 131072:
+            tj = json.load(open(tpath)).get(precision)
+            if tj:
+                traffic, traffic_src = tj.get("traffic_bytes_per_launch"), "profiles/r2_hbm_traffic.json (rocprofv3 --pmc passes of this command)"
+        st = L["status"].cpu().numpy()
+        steps_col = L["summary"][_abi.SUM_STEPS].cpu().numpy()
+        return {
+            "value": value, "unit": "trajectories/s", "ms_per_step": L["elapsed"] / args.steps * 1e3, "dtype": precision,
+            "trajectory_steps_per_s": L["phys_total"] * args.steps / L["elapsed"],
             "steps_per_trajectory": {"mean": float(steps_col.mean()), "max": float(steps_col.max()),
-                                     "physics_mean": phys_steps / n},
-            "lane_utilisation": phys_steps / (64.0 * wave_iters) if wave_iters else None,
-            "pipelined": pipelined,
+                                     "physics_mean": L["phys_steps"] / n},
+            "lane_utilisation": L["phys_steps"] / (64.0 * L["wave_iters"]) if L["wave_iters"] else None,
             "end_reasons": {k: int(np.sum((st & 0xFF) == v)) for k, v in
                             (("max_time", 0), ("ground", 1), ("altitude_100km", 2), ("coast", 3), ("apogee", 4))},
             "nan_fraction": float(np.mean((st & _abi.ST_NAN) != 0)),
-            "kernel_ms": {"erpl_flight": fl, "erpl_rail": rl, "per_launch_flight_ms": [round(x, 3) for x in flight_ms]},
+            "kernel_ms": {"gpu_ms_per_launch": per_launch_ms, "erpl_flight_dispatch_mean": fl, "erpl_rail_dispatch_mean": rl,
+                          "launches_in_flight": max(depth, 1),
+                          "per_dispatch_flight_ms": [round(x, 3) for x in L["flight_ms"]]},
             "roofline": {
-                "bound": "valu", "achieved": achieved_tf, "peak": PEAK_FP32_VECTOR_TFLOPS if prec == _abi.PREC_F32 else PEAK_FP32_VECTOR_TFLOPS / 2,
-                "unit": "TFLOP/s",
-                "frac": achieved_tf / (PEAK_FP32_VECTOR_TFLOPS if prec == _abi.PREC_F32 else PEAK_FP32_VECTOR_TFLOPS / 2),
-                "traffic": traffic,
-                "kernel": "erpl_flight_" + args.precision,
-                "algorithmic_flops_per_step": FLOPS_PER_STEP, "rk4_steps_per_launch": phys_steps,
-                "note": "non-MFMA vector-ALU bound (SURVEY 8d); peak = fp32 vector (= f32 MFMA) rate",
+                "bound": "valu", "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tf / peak,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": "erpl_flight_" + {"f32": "f32", "f64": "f64", "f64_fast": "f64f"}[precision],
+                "algorithmic_flops_per_step": FLOPS_PER_STEP, "rk4_steps_per_launch": L["phys_steps"],
+                "launch_duration_ms": per_launch_ms,
+                "per_dispatch": {"duration_ms": fl, "achieved": dispatch_tf, "frac": dispatch_tf / peak,
+                                 "note": "what rocprofv3 --kernel-trace reports per dispatch; dispatches overlap"},
+                "note": "non-MFMA vector-ALU bound (SURVEY 8d); peak = vector rate of the dtype",
                 "hbm": {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                         "frac": hbm_gbps / PEAK_HBM_GBPS, "algorithmic_bytes_per_launch": algo_bytes},
             },
         }
 
-    # ---------------- CPU baseline + parity (N = 1 only, rank 0, outside the timed region) ----------------
+    main_leg = timed_leg(args.precision)
+    second = None
+    if not args.no_second_leg and args.precision != "f64_fast":
+        second = timed_leg("f64_fast")
+
+    out = None
+    if rank == 0:
+        total_traj = n * world
+        out = {"metric": "Monte Carlo trajectories/sec (whole node) + apogee-match rate"}
+        body = leg_json(main_leg)
+        out.update({"value": body.pop("value"), "unit": body.pop("unit"), "n_gpus": world, "steps": args.steps,
+                    "warmup": args.warmup, "ms_per_step": body.pop("ms_per_step"), "higher_is_better": True,
+                    "scaling": "weak", "vs_baseline": None, "dtype": body.pop("dtype"), "data": "synthetic",
+                    "config": {
+                        "workload": f"{args.workload}: {n} dispersed 6-DOF samples/GPU ({total_traj} total), "
+                                    f"{args.motor} motor, reference dispersion model, "
+                                    f"{'CSV base wind K=6' if csv else 'synthetic wind K=100'}, "
+                                    f"rail dt=0.01 + RK4 dt=0.005, "
+                                    f"{'to first-descent apogee' if flags else 'full reference termination logic'}",
+                        "samples_per_gpu": n, "precision": args.precision, "passes_in_flight": max(depth, 1),
+                        "parallelism": f"sample-shard x{world}" + (" + RCCL all-gather of [16,n] summaries overlapped with the following passes" if world > 1 else ""),
+                    }})
+        out.update(body)
+        if second is not None:
+            out["f64_fast"] = leg_json(second)
+
+    # ---------------- parity + CPU baseline (N = 1 only, rank 0, outside the timed region) ----------------
     if rank == 0 and world > 1:
         out["cpu_baseline"] = None   # measured by the N = 1 run only (the host cores are shared by the ranks)
+    if rank == 0 and world == 1 and not args.no_parity:
+        # the fp64 reference-order gate kernel on the SAME shard: the per-sample reference for every timed build
+        gs, gt = eng.run(as_precision(db64, _abi.PREC_F64), flags=flags)
+        torch.cuda.synchronize()
+        gs, gt = gs.cpu().numpy(), gt.cpu().numpy()
+        rep = match_report(gs, gt, main_leg["summary"].cpu().numpy(), main_leg["status"].cpu().numpy())
+        out["apogee_match_rate"] = rep["apogee_match_rate_0p1pct"]
+        out["parity"] = {"timed_shard_vs_fp64_gate_kernel": rep}
+        if second is not None:
+            rep2 = match_report(gs, gt, second["summary"].cpu().numpy(), second["status"].cpu().numpy())
+            out["f64_fast"]["apogee_match_rate"] = rep2["apogee_match_rate_0p1pct"]
+            out["f64_fast"]["parity"] = {"timed_shard_vs_fp64_gate_kernel": rep2}
     if rank == 0 and world == 1 and (args.cpu_seconds > 0 or not args.no_parity):
         from oracle import oracle as orc
         cores = host_cores()
@@ -308,45 +383,48 @@ def main():
             m = min(n, 256 * cores)
             cpu_t, osum, ostat = 0.0, None, None
             for _attempt in range(3):  # grow the sample until it is a 10-30 s measurement
-                hb = host_slice(db, m)
+                hb = host_slice(db64, m)
                 t1 = time.perf_counter()
                 osum, ostat = orc.run_batch(cfg, hb, flags=flags, threads=cores)
                 cpu_t = time.perf_counter() - t1
                 if cpu_t >= 0.6 * args.cpu_seconds or m >= n:
                     break
                 m = int(min(n, max(m + 1, m * args.cpu_seconds / max(cpu_t, 1e-3))))
+            # RK4 steps with physics in them (the GPU's unit): the oracle brute-forces the ~57 k no-op steps
+            # of every non-finite trajectory, the kernels fast-forward them; count the same m samples' physics
+            # steps with the gate kernel (identical trajectories)
+            sub = DeviceBatch.from_host(hb, device, _abi.PREC_F64)
+            eng.run(sub, flags=flags)
+            phys_m, _ = eng.last_stats()
             out["cpu_baseline"] = {
                 "value": m / cpu_t, "unit": "trajectories/s", "cores": cores, "kind": "port",
                 "sample": f"first {m} samples of rank 0's shard, CPU oracle (C fp64, OpenMP, {cores} threads), {cpu_t:.1f} s",
-                "trajectory_steps_per_s": float(osum[_abi.SUM_STEPS].sum() / cpu_t),
+                "all_loop_steps_per_s": float(osum[_abi.SUM_STEPS].sum() / cpu_t),
+                "physics_steps_per_s": float(phys_m / cpu_t),
+                "note": "physics_steps_per_s is the unit of the GPU's trajectory_steps_per_s; all_loop_steps_per_s also counts the no-op steps of non-finite trajectories the oracle runs to max_time",
             }
-            got = sm[:, :m]
-            e_fa = relerr(got[_abi.SUM_FIRST_APOGEE_ALT], osum[_abi.SUM_FIRST_APOGEE_ALT])
-            e_ap = relerr(got[_abi.SUM_APOGEE_ALT], osum[_abi.SUM_APOGEE_ALT])
-            out["parity"] = {
-                "shard_sample": {"n": m, "precision": args.precision,
-                                 "first_apogee_match_rate_0p1pct": float(np.mean(e_fa <= 1e-3)),
-                                 "apogee_argmax_match_rate_0p1pct": float(np.mean(e_ap <= 1e-3)),
-                                 "same_end_reason": float(np.mean((st[:m] & 0xFF) == (ostat & 0xFF)))}}
+            if not args.no_parity:
+                for L, dst in ((main_leg, out), (second, out.get("f64_fast"))):
+                    if L is None:
+                        continue
+                    got_s, got_t = L["summary"][:, :m].cpu().numpy(), L["status"][:m].cpu().numpy()
+                    dst["parity"]["timed_shard_sample_vs_cpu_oracle"] = match_report(osum, ostat, got_s, got_t)
         if not args.no_parity:
-            # BASELINE configs[1]: 1 k reference-faithful samples (seed=i stream, CSV wind), fp64 gate
+            # BASELINE configs[1]: 1 k reference-faithful samples (seed=i stream, CSV wind) against the CPU oracle
             pl = flatten.generate_parameter_samples(sampling.DEFAULT_UNCERTAINTY, 1000)
             hbr = flatten.dispersed_batch(rocket, models.LiquidMotor(), wm, EXAMPLE_IC, pl, CSV_ALT, CSV_WIND)
             cfg_l = flatten.config_from_objects(rocket, models.LiquidMotor(), atm)
             osum, ostat = orc.run_batch(cfg_l, hbr, threads=cores)
             eng.set_config(cfg_l)
             res = {}
-            for name, p in (("f64", _abi.PREC_F64), ("f32", _abi.PREC_F32)):
+            for name, p in _abi.PRECISIONS.items():
                 dbr = DeviceBatch.from_host(hbr, device, p)
                 s2, st2 = eng.run(dbr)
                 torch.cuda.synchronize()
-                s2 = s2.cpu().numpy()
-                res[name] = {
-                    "apogee_match_rate_0p1pct": float(np.mean(relerr(s2[_abi.SUM_APOGEE_ALT], osum[_abi.SUM_APOGEE_ALT]) <= 1e-3)),
-                    "first_apogee_match_rate_0p1pct": float(np.mean(relerr(s2[_abi.SUM_FIRST_APOGEE_ALT], osum[_abi.SUM_FIRST_APOGEE_ALT]) <= 1e-3)),
-                }
-            out.setdefault("parity", {})["cfg2_set_r_1k"] = res
-            out["apogee_match_rate"] = res["f64"]["apogee_match_rate_0p1pct"]
+                r = match_report(osum, ostat, s2.cpu().numpy(), st2.cpu().numpy())
+                r.pop("by_reference_class")
+                res[name] = r
+            out["parity"]["cfg2_set_r_1k_vs_cpu_oracle"] = res
             eng.set_config(cfg)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -222,13 +222,15 @@ struct erpl_ctx {
   ErplTables h_tables;            // host copy (scalars are passed to the kernels by value)
   ErplTables* d_tables = nullptr;
   ErplSlot slot[ERPL_MAX_OVERLAP];
-  int depth = 2;                  // slots erpl_mc_submit_batch cycles through
+  int depth = 3;                  // slots erpl_mc_submit_batch cycles through (measured best at 131 072 samples)
   int64_t submitted = 0;          // tickets handed out
   int last_slot = 0;              // slot of the most recent batch (erpl_mc_last_stats)
   int64_t reserve_n = 0;          // erpl_mc_reserve request, applied to a slot when it is first used
   int chunk = 0;
   int waves = 0;   // 0 = choose by batch size
-  int block = 256, max_blocks = 0, refill = 1;   // refill as soon as a lane is idle (measured best: 1..4)
+  // one wave per workgroup: a finished wave frees its slot for the next batch at once (measured 2-5 %
+  // over 256-thread workgroups, alone and overlapped); refill as soon as a lane is idle (best: 1..4)
+  int block = 64, max_blocks = 0, refill = 1;
   bool profiling = false;
   long long profiled_runs = 0;
   hipEvent_t ev[3 * ERPL_PROFILE_RING] = {};
@@ -306,7 +308,7 @@ void fill_common_args(const erpl_ctx* c, const erpl_batch* b, ErplKArgs& a) {
 }
 
 // Rail + flight kernels of one batch through slot `si`, on stream `st`.
-int enqueue_batch(erpl_ctx* c, int si, const erpl_batch* b, const erpl_out* o, hipStream_t st) {
+int enqueue_batch(erpl_ctx* c, int si, const erpl_batch* b, const erpl_out* o, hipStream_t st, int in_flight) {
   ErplSlot& s = c->slot[si];
   int rc = slot_init(s);
   if (rc != ERPL_OK) return rc;
@@ -327,10 +329,13 @@ int enqueue_batch(erpl_ctx* c, int si, const erpl_batch* b, const erpl_out* o, h
   a.counters = s.d_counters;
   a.refill_threshold = c->refill;
   const ErplTables& T = c->h_tables;
-  const int max_blocks = c->max_blocks > 0 ? c->max_blocks : c->n_cu * 8;
-  // the three-wave build pays once the batch refills three resident waves per SIMD a few times over
-  // (measured +4..12 % from 3 rounds up; between 1 and 3 rounds the rounding of "rounds" decides)
-  a.waves_per_simd = c->waves ? c->waves : ((b->n >= (int64_t)c->n_cu * 4 * 64 * 3 * 3) ? 3 : 2);
+  const int max_blocks = c->max_blocks > 0 ? c->max_blocks : c->n_cu * 8 * (256 / c->block);
+  // the three-wave build pays once three resident waves per SIMD stay busy: a batch that refills them a
+  // few times over (measured +4..12 % from 3 rounds up; between 1 and 3 rounds the rounding of "rounds"
+  // decides), or several batches in flight sharing the SIMDs (131 072 samples x 3 deep: +13 %)
+  const bool dense = b->n >= (int64_t)c->n_cu * 4 * 64 * 3 * 3 ||
+                     (in_flight >= 2 && b->n * in_flight >= (int64_t)c->n_cu * 4 * 64 * 3);
+  a.waves_per_simd = c->waves ? c->waves : (dense ? 3 : 2);
   // step-chunked launches with compaction in between (erpl_mc_set_chunk); every lane ends within
   // ceil(max_time / dt) + 1 steps, so that many steps' worth of chunks drains the queue
   int n_phases = 1;
@@ -454,7 +459,7 @@ int erpl_mc_run_batch(erpl_ctx* c, const erpl_batch* b, const erpl_out* o, void*
   int rc = check_batch(c, b, o);
   if (rc != ERPL_OK || b->n == 0) return rc;
   HIP_TRY(hipSetDevice(c->device));
-  return enqueue_batch(c, 0, b, o, (hipStream_t)stream);
+  return enqueue_batch(c, 0, b, o, (hipStream_t)stream, 1);
 }
 
 int erpl_mc_set_overlap(erpl_ctx* c, int depth) {
@@ -481,7 +486,7 @@ int erpl_mc_submit_batch(erpl_ctx* c, const erpl_batch* b, const erpl_out* o, vo
   // inputs written on the caller's stream so far are visible to the batch
   HIP_TRY(hipEventRecord(s.in_ready, (hipStream_t)stream));
   HIP_TRY(hipStreamWaitEvent(s.stream, s.in_ready, 0));
-  rc = enqueue_batch(c, si, b, o, s.stream);
+  rc = enqueue_batch(c, si, b, o, s.stream, c->depth);
   if (rc != ERPL_OK) return rc;
   s.ticket = ++c->submitted;
   if (ticket) *ticket = s.ticket;
@@ -704,6 +709,58 @@ int erpl_mc_extract_histories(erpl_ctx* c, const erpl_batch* b, int64_t sample, 
   a.summary = out; a.traj = const_cast<double*>(traj); a.traj_cap = m; a.n_traj = sample;
   int rc = erpl_launch_extract_f64(a, &T.s64, time_offset, stream);
   if (rc != 0) return fail(ERPL_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return ERPL_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// AR(1) turbulence over the altitude knots + mean wind for n samples at once (environment.py:161-198 /
+// :242-263 with caller-supplied standard normals): one thread per (component, sample), sequential over
+// the k knots, every access coalesced along the sample index.  fp64 recursion whatever the output type.
+template <typename OUT>
+__global__ __launch_bounds__(256) void erpl_wind_ar1(const int64_t n, const int k, const double* __restrict__ g,
+                                                     const double* __restrict__ sigma, const double* __restrict__ rho,
+                                                     const double* __restrict__ innov, const double* __restrict__ base,
+                                                     const double* __restrict__ scale, const double* __restrict__ mean_u,
+                                                     const double* __restrict__ mean_v, OUT* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 3 * n) return;
+  const int c = (int)(idx / n);
+  const int64_t s = idx - (int64_t)c * n;
+  const double comp = (c == 2) ? 0.3 : 1.0;   // vertical component: 30 % of the horizontal turbulence
+  const double m = (c == 0) ? mean_u[s] : ((c == 1) ? mean_v[s] : 0.0);
+  double t = 0.0;
+  for (int i = 0; i < k; ++i) {
+    const double z = g[(int64_t)(i * 3 + c) * n + s];
+    t = (i == 0) ? (sigma[0] * comp) * z : rho[i] * t + (innov[i] * comp) * z;
+    const double b = base ? base[i * 3 + c] : 0.0;
+    out[(int64_t)(i * 3 + c) * n + s] = (OUT)((b + scale[i] * m) + t);
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int erpl_mc_synth_wind(erpl_ctx* c, int64_t n, int32_t k, const double* normals, const double* sigma, const double* rho,
+                       const double* innov, const double* base, const double* scale, const double* mean_u,
+                       const double* mean_v, void* wind, int32_t precision, void* stream) {
+  if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
+  if (n < 0 || k < 0 || k > ERPL_MAX_WIND_KNOTS) return fail(ERPL_ERR_INVALID, "bad size (n=%lld k=%d)", (long long)n, k);
+  if (n == 0 || k == 0) return ERPL_OK;
+  if (!normals || !sigma || !rho || !innov || !scale || !mean_u || !mean_v || !wind) return fail(ERPL_ERR_INVALID, "NULL buffer");
+  if (precision != ERPL_PREC_F64 && precision != ERPL_PREC_F32 && precision != ERPL_PREC_F64_FAST)
+    return fail(ERPL_ERR_INVALID, "unknown precision %d", precision);
+  HIP_TRY(hipSetDevice(c->device));
+  const int block = 256;
+  const int64_t grid = (3 * n + block - 1) / block;
+  if (precision == ERPL_PREC_F32)
+    hipLaunchKernelGGL(erpl_wind_ar1<float>, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream, n, (int)k, normals, sigma,
+                       rho, innov, base, scale, mean_u, mean_v, (float*)wind);
+  else
+    hipLaunchKernelGGL(erpl_wind_ar1<double>, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream, n, (int)k, normals, sigma,
+                       rho, innov, base, scale, mean_u, mean_v, (double*)wind);
+  HIP_TRY(hipGetLastError());
   return ERPL_OK;
 }
 

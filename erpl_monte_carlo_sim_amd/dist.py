@@ -49,15 +49,14 @@ def all_gather_summaries(summary, status, n_total, group=None):
     return full_s, full_t
 
 
-def run_sharded(host_batch, runner, group=None):
-    """Integrate `host_batch` (all samples, identical on every rank) with this rank's `runner` on
-    its contiguous shard and gather.  runner(HostBatch) -> (summary [S, m] tensor, status [m] tensor).
-    Returns NumPy (summary [S, n], status [n]) identical on every rank."""
+def run_local_shard(n_total, local_batch, runner, group=None):
+    """`local_batch` holds THIS rank's contiguous shard [lo, hi) of an n_total-sample batch (None or empty
+    when the shard is empty): integrate it with `runner` and all-gather.  runner(HostBatch) -> (summary
+    [S, m] tensor, status [m] tensor).  Returns NumPy (summary [S, n_total], status [n_total]), identical
+    on every rank.  Host preparation per rank is proportional to n_total / world."""
     rank, ws = world()
-    n = host_batch.n
-    lo, hi, _ = shard_bounds(n, rank, ws)
-    if hi > lo:
-        summ, stat = runner(host_batch.take(np.arange(lo, hi)))
+    if local_batch is not None and local_batch.n > 0:
+        summ, stat = runner(local_batch)
     else:
         summ = stat = None
     if ws == 1:
@@ -66,5 +65,16 @@ def run_sharded(host_batch, runner, group=None):
         ref_dev = torch.device("cuda", torch.cuda.current_device()) if torch.distributed.get_backend(group) == "nccl" else torch.device("cpu")
         summ = torch.empty((16, 0), dtype=torch.float64, device=ref_dev)
         stat = torch.empty((0,), dtype=torch.int32, device=ref_dev)
-    full_s, full_t = all_gather_summaries(summ, stat, n, group)
+    elif torch.distributed.get_backend(group) != "nccl":   # gloo (CPU tests, single-GPU rehearsals) gathers host tensors
+        summ, stat = summ.cpu(), stat.cpu()
+    full_s, full_t = all_gather_summaries(summ, stat, n_total, group)
     return full_s.cpu().numpy(), full_t.cpu().numpy()
+
+
+def run_sharded(host_batch, runner, group=None):
+    """Integrate `host_batch` (all samples, identical on every rank) with this rank's `runner` on
+    its contiguous shard and gather (see run_local_shard, which avoids building the other ranks' samples)."""
+    rank, ws = world()
+    lo, hi, _ = shard_bounds(host_batch.n, rank, ws)
+    local = host_batch.take(np.arange(lo, hi)) if hi > lo else None
+    return run_local_shard(host_batch.n, local, runner, group)

@@ -11,12 +11,45 @@
 import numpy as np
 
 from . import _abi
-from .models import LiquidMotor, SolidMotor
+from .models import LiquidMotor, SolidMotor, knot_constants
 
 
 class UnsupportedModel(TypeError):
     """Raised when a duck-typed object cannot be flattened (the kernels hard-code the
     reference's model equations; there is no CPU fallback)."""
+
+
+# Methods of the reference's model classes whose equations the kernels (or the vectorised host
+# preparation) hard-code.  A user subclass - or an unrelated duck-typed class - that defines one of them
+# would be silently ignored by the GPU path, so it is refused (SURVEY 8b: there is no CPU fallback).
+_KNOWN_MODELS = ("Rocket", "SolidMotor", "LiquidMotor", "StandardAtmosphere", "WindModel")
+_HARD_CODED = {
+    "rocket": ("get_mass_properties", "get_aerodynamic_coefficients", "get_dynamic_cp"),            # rocket.py:105-218
+    "motor": ("get_thrust", "get_mass_flow_rate", "get_propellant_remaining", "perturb_for_monte_carlo"),  # motor.py:54-186
+    "atmosphere": ("get_properties", "get_gravity"),                                                 # environment.py:26-108
+    "wind_model": ("get_wind_at_altitude", "generate_stochastic_profile", "perturb_wind_profile",
+                   "power_law_profile"),                                                            # environment.py:118-276
+}
+
+
+def reject_overrides(obj, role):
+    """Raise UnsupportedModel if `obj` (playing `role`) redefines a method the GPU path hard-codes: in a
+    subclass of one of the known model classes (the reference's or this package's), on the instance, or
+    in a class unrelated to them."""
+    methods = _HARD_CODED[role]
+    patched = [m for m in methods if m in getattr(obj, "__dict__", {})]
+    if patched:
+        raise UnsupportedModel(f"{role}: instance attribute(s) {patched} replace methods the HIP kernels hard-code")
+    for cls in type(obj).__mro__:
+        if cls is object:
+            break
+        if cls.__name__ in _KNOWN_MODELS:
+            return            # everything from here up is the model the kernels implement
+        over = [m for m in methods if m in cls.__dict__]
+        if over:
+            raise UnsupportedModel(
+                f"{role}: class {cls.__name__} overrides {over}; the HIP kernels hard-code the reference's "
+                f"equations for these and there is no CPU fallback")
 
 
 def euler_to_quaternion(roll, pitch, yaw):
@@ -52,6 +85,9 @@ def _fill(arr, values, cap, what):
 def config_from_objects(rocket, motor, atmosphere, dt_initial=0.01, max_time=300.0,
                         rail_length=18.288, pitch_damping=20.0, yaw_damping=20.0):
     """Build the shared `erpl_config`.  Field-by-field sources are listed in include/erpl_mc.h."""
+    reject_overrides(rocket, "rocket")
+    reject_overrides(motor, "motor")
+    reject_overrides(atmosphere, "atmosphere")
     c = _abi.ErplConfig()
     for name in ("diameter", "center_of_mass_dry", "Ixx_dry", "Iyy_dry", "reference_area",
                  "reference_diameter", "cp_location", "fin_root_chord", "fin_tip_chord",
@@ -316,7 +352,7 @@ def legacy_wind_profiles(wind_model, alt, seeds, base=None, speed=None, cdir=Non
     import ctypes as C
     seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
     n, K = seeds.size, len(alt)
-    sigma, rho, innov = wind_model._knot_constants(alt)
+    sigma, rho, innov = knot_constants(wind_model, alt)
     f = lambda v: np.ascontiguousarray(v, dtype=np.float64)
     sigma, rho, innov = f(sigma), f([0.0] + list(rho[1:])), f([0.0] + list(innov[1:]))
     ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
@@ -337,7 +373,7 @@ def legacy_wind_profiles(wind_model, alt, seeds, base=None, speed=None, cdir=Non
 def _ar1_profiles(wind_model, alt, g, mean_u=None, mean_v=None, base=None):
     """AR(1) turbulence of environment.py:161-198 / :242-263 for all samples: g [3K, n] holds each
     sample's normals in draw order (u, v, w per knot); returns [K, 3, n]."""
-    sigma, rho, innov = wind_model._knot_constants(alt)
+    sigma, rho, innov = knot_constants(wind_model, alt)
     K, n = len(sigma), g.shape[1]
     out = np.empty((K, 3, n))
     zero = np.zeros(n)
@@ -370,6 +406,7 @@ def dispersed_batch(rocket, motor, wind_model, base_initial_conditions, params_l
     the 100-knot synthetic profile).  `planar=True` zeroes every out-of-plane input (Set P, SURVEY
     §8d).  `params_list` is the reference's list of dicts or the dict of arrays of
     generate_parameter_arrays."""
+    reject_overrides(wind_model, "wind_model")
     use_base = base_wind_profile is not None and base_altitude_profile is not None
     alt = (np.asarray(base_altitude_profile, dtype=np.float64) if use_base else np.linspace(0, 25000, 100))
     if not isinstance(params_list, dict) and len(params_list) == 0:

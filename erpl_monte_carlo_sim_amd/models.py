@@ -152,6 +152,22 @@ class StandardAtmosphere:
         self.stratosphere_temp = 216.65
 
 
+
+def knot_constants(wind_model, altitudes):
+    """Per-knot turbulence sigma, AR(1) correlation and innovation sigma of a WindModel-shaped object
+    (this package's or the reference's: only `turbulence_intensity` and `correlation_length` are read)
+    (environment.py:161, :176-181, :189 == :242, :249-255)."""
+    alt = [np.float64(a) for a in altitudes]
+    sigma = [wind_model.turbulence_intensity * np.exp(-a / 2000.0) for a in alt]
+    rho, innov = [None], [None]
+    for i in range(1, len(alt)):
+        dz = max(alt[i] - alt[i - 1], 1e-6)
+        r = np.clip(np.exp(-dz / wind_model.correlation_length), 0.1, 0.95)
+        rho.append(r)
+        innov.append(sigma[i] * np.sqrt(max(1 - r ** 2, 0.01)))
+    return sigma, rho, innov
+
+
 class WindModel:
     """Wind-profile preparation of environment.py:110-265 (host-side input prep)."""
 
@@ -173,17 +189,7 @@ class WindModel:
         return alt, np.vstack([data["u"], data["v"], w]).T
 
     def _knot_constants(self, altitudes):
-        """Per-knot turbulence sigma, AR(1) correlation and innovation sigma
-        (environment.py:161, :176-181, :189 == :242, :249-255)."""
-        alt = [np.float64(a) for a in altitudes]
-        sigma = [self.turbulence_intensity * np.exp(-a / 2000.0) for a in alt]
-        rho, innov = [None], [None]
-        for i in range(1, len(alt)):
-            dz = max(alt[i] - alt[i - 1], 1e-6)
-            r = np.clip(np.exp(-dz / self.correlation_length), 0.1, 0.95)
-            rho.append(r)
-            innov.append(sigma[i] * np.sqrt(max(1 - r ** 2, 0.01)))
-        return sigma, rho, innov
+        return knot_constants(self, altitudes)
 
     # -- stochastic profiles (legacy RandomState stream, draw order u, v, w per knot) -------
     def perturb_wind_profile(self, altitudes, base_profile, random_state=None):

@@ -76,6 +76,7 @@ class FlightSimulator:
 
     def simulate_flight(self, initial_conditions, wind_profile=None, altitude_profile=None):
         """Simulate one flight (simulator.py:127-293)."""
+        flatten.reject_overrides(self.wind_model, "wind_model")   # the kernels interpolate the table themselves
         eng = shared_engine(self.device)
         eng.set_config(self._config())
         hb = flatten.single_flight_batch(self.rocket, self.motor, initial_conditions, wind_profile, altitude_profile)

@@ -194,7 +194,7 @@ int erpl_mc_run_batch(erpl_ctx* ctx, const erpl_batch* batch, const erpl_out* ou
  * (inputs written there are visible), and returns a ticket; it does NOT make `hip_stream` wait.
  * erpl_mc_wait_batch makes `hip_stream` wait on the device for that batch (ticket < 0: for every batch
  * submitted so far); the host never blocks.  Output buffers belong to the batch until then.  Results
- * are bitwise those of erpl_mc_run_batch.  depth 1..8, default 2; changing it waits for work in flight. */
+ * are bitwise those of erpl_mc_run_batch.  depth 1..8, default 3; changing it waits for work in flight. */
 #define ERPL_MAX_OVERLAP 8
 int erpl_mc_set_overlap(erpl_ctx* ctx, int depth);
 int erpl_mc_submit_batch(erpl_ctx* ctx, const erpl_batch* batch, const erpl_out* out, void* hip_stream, int64_t* ticket);
@@ -202,7 +202,7 @@ int erpl_mc_wait_batch(erpl_ctx* ctx, int64_t ticket, void* hip_stream);
 /* Host-blocking wait for everything this context has enqueued. */
 int erpl_mc_synchronize(erpl_ctx* ctx);
 
-/* Launch geometry knobs (tuning / tests): threads per workgroup, max resident workgroups for the
+/* Launch geometry knobs (tuning / tests): threads per workgroup (default 64), max workgroups of the
  * persistent flight kernel (0 = library default), lane-refill threshold. */
 int erpl_mc_set_launch(erpl_ctx* ctx, int block_threads, int max_blocks, int refill_threshold);
 
@@ -258,6 +258,19 @@ int erpl_mc_legacy_wind_profiles(const uint32_t* seeds, int64_t n, int32_t k, co
                                  const double* rho, const double* innov, const double* base,
                                  const double* mean_scale, const double* speed, const double* cdir,
                                  const double* sdir, double* wind, int32_t threads);
+
+/* On-device wind-table synthesis for the 100 k - 10 M throughput sets: the AR(1) turbulence
+ * recursion over the k altitude knots of environment.py:161-198 / :242-263 plus the mean wind, for n
+ * samples at once, from caller-supplied standard normals (counter-based device RNG; NOT the MT19937
+ * streams of the parity sets).  wind[i][c][s] = base[i][c] + scale[i] * mean_c[s] + t_i, with
+ * t_0 = sigma[0] f_c z, t_i = rho[i] t_{i-1} + innov[i] f_c z, f = (1, 1, 0.3), z = normals[i][c][s],
+ * mean_2 = 0.  CSV mode (monte_carlo.py:268-280): base = the baseline profile, scale = 1, mean = the
+ * uniform (speed, direction) offset; synthetic mode (:282-288): base = NULL, scale[i] = (alt_i/10)^p,
+ * mean = speed * (cos, sin)(direction).  All pointers are device memory; normals / wind are [k][3][n];
+ * wind is float for ERPL_PREC_F32, double otherwise (the recursion itself always runs in fp64). */
+int erpl_mc_synth_wind(erpl_ctx* ctx, int64_t n, int32_t k, const double* normals, const double* sigma,
+                       const double* rho, const double* innov, const double* base, const double* scale,
+                       const double* mean_u, const double* mean_v, void* wind, int32_t precision, void* hip_stream);
 
 /* Known-answer evaluation ON THE DEVICE (tests): one function of the hot path per lane, through the
  * device functions the flight kernel of `batch->precision` inlines.  Case j (0 <= j < m) uses the

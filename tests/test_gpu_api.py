@@ -118,22 +118,69 @@ def test_run_monte_carlo_optimized_raises_like_reference():
 
 
 def test_run_monte_carlo_fp32_and_synthetic_wind():
+    """precision = "f32", SolidMotor, no base profile (100-knot synthetic wind), seed-42 stream: the
+    analysis must be exactly what the outlier rules give on the summaries the same engine returns for
+    the same samples - or the reference's ValueError when nothing survives them."""
+    from erpl_monte_carlo_sim_amd import analysis
     mc = E.MonteCarloAnalyzer(E.Rocket(), E.SolidMotor(), E.StandardAtmosphere(), E.WindModel(), verbose=False)
     mc.precision = "f32"
     mc.n_trajectories = 0
-    try:
-        out = mc.run_monte_carlo(dict(H.EXAMPLE_IC), n_samples=64, optimized=True)
-        assert "performance" in out and out["performance"]["simulations_per_second"] > 0
-        n = out["n_samples"] + out["n_outliers"]
-    except ValueError:
-        n = 64
-    assert n == 64
+    n = 64
+    params = mc._generate_parameter_samples_vectorized(n)
+    summ, status, traj, lo = mc.run_batch_arrays(dict(H.EXAMPLE_IC), params)
+    assert summ.shape == (16, n) and status.shape == (n,) and traj is None and lo == 0
+    bad = analysis.outlier_mask(summ[_abi.SUM_APOGEE_ALT], summ[_abi.SUM_RANGE], summ[_abi.SUM_FLIGHT_TIME])
+    n_valid = int(n - bad.sum())
+    if n_valid == 0:
+        with pytest.raises(ValueError, match="No physically reasonable"):
+            mc.run_monte_carlo(dict(H.EXAMPLE_IC), n_samples=n, optimized=True)
+    else:
+        out = mc.run_monte_carlo(dict(H.EXAMPLE_IC), n_samples=n, optimized=True)
+        assert out["n_samples"] == n_valid and out["n_outliers"] == n - n_valid and out["n_failed"] == 0
+        assert out["performance"]["simulations_per_second"] > 0 and out["performance"]["gpus_used"] == 1
+        valid = np.where(~bad)[0]
+        assert [r["simulation_id"] for r in out["results"]] == list(valid)
+        assert out["apogee_altitude"]["max"] == summ[_abi.SUM_APOGEE_ALT][valid].max()
+    # the 100-knot synthetic table really was used, and every sample ended for a reason
+    assert np.all((status & 0xFF) <= _abi.END_COAST)
+
+
+def test_trajectory_split_does_not_change_summaries():
+    """run_monte_carlo integrates the samples that carry a trajectory (the first n_trajectories) in a
+    small capture batch and the rest through the specialised build: same bits as one batch."""
+    res = {}
+    for n_traj in (0, 5, 40):
+        mc = E.MonteCarloAnalyzer(E.Rocket(), E.LiquidMotor(), E.StandardAtmosphere(), E.WindModel(), verbose=False)
+        mc.base_altitude_profile, mc.base_wind_profile = H.CSV_ALT, H.CSV_WIND
+        mc.n_trajectories = n_traj
+        params = mc._generate_parameter_samples(40)
+        summ, status, traj, lo = mc.run_batch_arrays(dict(H.EXAMPLE_IC), params)
+        res[n_traj] = (summ, status)
+        assert (traj is None) == (n_traj == 0)
+        if traj is not None:
+            assert len(traj[0]) == n_traj
+    for n_traj in (5, 40):
+        assert np.array_equal(res[0][0], res[n_traj][0], equal_nan=True)
+        assert np.array_equal(res[0][1], res[n_traj][1])
+
+
+def test_user_subclass_overriding_model_method_is_refused():
+    from erpl_monte_carlo_sim_amd.flatten import UnsupportedModel
+
+    class MyMotor(E.LiquidMotor):
+        def get_thrust(self, t, p):      # the kernels would silently ignore this
+            return 1.0
+
+    sim = E.FlightSimulator(E.Rocket(), MyMotor(), E.StandardAtmosphere(), E.WindModel())
+    with pytest.raises(UnsupportedModel, match="get_thrust"):
+        sim.simulate_flight(dict(H.EXAMPLE_IC))
 
 
 def test_run_monte_carlo_device_large_n():
     """Throughput form (cfg 3-5): on-device dispersions + integration + on-device statistics."""
     mc = E.MonteCarloAnalyzer(E.Rocket(), E.LiquidMotor(), E.StandardAtmosphere(), E.WindModel(), verbose=False)
     out = mc.run_monte_carlo_device(dict(H.EXAMPLE_IC), 20000, planar=True)
+    assert out["performance"]["precision"] == "f64_fast"     # the parity-preserving build is the default
     assert out["n_samples"] + out["n_outliers"] == 20000
     assert out["n_samples"] > 15000                      # planar dispersions are mostly healthy
     assert 20000 < out["apogee_altitude"]["mean"] < 32000

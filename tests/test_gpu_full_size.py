@@ -1,0 +1,171 @@
+"""Full-size GPU tests: BASELINE config 5's per-GPU share (10 M samples / 8 GPUs = 1.25 M: CSV base
+wind + parachute-deploy event + per-GPU compaction) and the N > 1 path with the GPU engine as the
+per-rank runner (two processes on one GPU, gloo)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from erpl_monte_carlo_sim_amd import _abi, flatten, models, sampling
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def relerr(a, b):
+    same = (a == b) | (np.isnan(a) & np.isnan(b))
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+        e = np.abs(a - b) / np.abs(b)
+    return np.where(same, 0.0, np.where(np.isnan(e), np.inf, e))
+
+
+def test_config5_share_csv_wind_parachute_compaction(oracle):
+    """1.25 M samples, CSV base profile (K = 6) + per-sample AR(1) + uniform offset, flights to the ground
+    under the parachute latch (simulator.py:366-377), step-chunked launches with compaction
+    (erpl_mc_set_chunk(2048)).  The oracle cannot integrate that many, so the full-size run is checked
+    through size-independent properties, and a 256-sample subset against the oracle incl. the parachute
+    flag and the landing."""
+    from erpl_monte_carlo_sim_amd.engine import DeviceBatch, TrajectoryEngine
+    eng = TrajectoryEngine(torch.device("cuda", 0))
+    n = 1_250_000
+    rocket, motor, wm = models.Rocket(), models.LiquidMotor(), models.WindModel()
+    cfg = H.make_config("liquid")
+    eng.set_config(cfg)
+    db = sampling.synthetic_dispersions(n, rocket, motor, wm, H.EXAMPLE_IC, eng.device, precision=_abi.PREC_F32, seed=55,
+                                        planar=True, base_altitude_profile=H.CSV_ALT, base_wind_profile=H.CSV_WIND, engine=eng)
+    try:
+        eng.set_chunk(2048)
+        s0, t0 = (x.clone() for x in eng.run(db))
+        eng.set_chunk(0)
+        eng.set_launch(256, 700, 8)
+        s1, t1 = eng.run(db)
+        torch.cuda.synchronize()
+        # compaction / launch geometry do not change a bit
+        assert torch.equal(t0, t1) and bool(((s0 == s1) | (s0.isnan() & s1.isnan())).all())
+        del s1, t1
+        # sample independence: a strided sub-batch alone reproduces its rows
+        eng.set_launch(64, 0, 1)
+        eng.set_chunk(2048)
+        idx = torch.arange(11, n, 4099, device=eng.device)
+        sub = DeviceBatch(db.ic[:, idx].contiguous(), db.rocket[:, idx].contiguous(), db.motor[:, idx].contiguous(),
+                          db.alt_grid, db.wind[:, :, idx].contiguous(), _abi.PREC_F32)
+        s2, t2 = eng.run(sub)
+        torch.cuda.synchronize()
+        assert torch.equal(t2, t0[idx]) and bool(((s2 == s0[:, idx]) | (s2.isnan() & s0[:, idx].isnan())).all())
+    finally:
+        eng.set_launch(64, 0, 1)
+        eng.set_chunk(0)
+    summ, status = s0.cpu().numpy(), t0.cpu().numpy()
+    reason = status & 0xFF
+    chute = (status & _abi.ST_CHUTE) != 0
+    assert np.all(reason <= _abi.END_COAST) and np.sum(np.bincount(reason, minlength=5)) == n
+    landed = reason == _abi.END_GROUND
+    # planar dispersions are healthy: nearly all land, under the parachute, near the 0.5 m threshold, slowly
+    assert landed.mean() > 0.97
+    assert chute[landed].mean() > 0.999
+    ok = landed & chute
+    assert np.all(summ[_abi.SUM_IMPACT_Z][ok] <= 0.5) and np.all(summ[_abi.SUM_FINAL_VZ][ok] <= 0)
+    assert np.median(summ[_abi.SUM_FINAL_VZ][ok]) == pytest.approx(-7.8, abs=0.5)      # -7.78 m/s
+    assert 20000 < np.median(summ[_abi.SUM_APOGEE_ALT][ok]) < 32000
+    assert np.all(summ[_abi.SUM_FLIGHT_TIME] <= cfg.max_time + 2 * cfg.dt_initial)
+    assert np.array_equal((status & _abi.ST_NAN) != 0, np.isnan(summ[_abi.SUM_APOGEE_ALT]))
+    fin = np.isfinite(summ[_abi.SUM_APOGEE_ALT]) & np.isfinite(summ[_abi.SUM_FIRST_APOGEE_ALT])
+    assert np.all(summ[_abi.SUM_APOGEE_ALT][fin] >= summ[_abi.SUM_FIRST_APOGEE_ALT][fin])
+    # the parachute latch can only be set below the deployment altitude on the way down: every latched sample came down
+    assert np.all((status[chute] & _abi.ST_APOGEE_LATCHED) != 0)
+    # 256-sample subset against the oracle
+    pick = np.sort(np.random.RandomState(5).choice(n, 256, replace=False))
+    tp = torch.as_tensor(pick, device=eng.device)
+    hb = flatten.HostBatch(len(pick), db.k_wind)
+    hb.ic = db.ic[:, tp].cpu().numpy(); hb.rocket = db.rocket[:, tp].cpu().numpy(); hb.motor = db.motor[:, tp].cpu().numpy()
+    hb.alt_grid = db.alt_grid.cpu().numpy(); hb.wind = db.wind[:, :, tp].double().cpu().numpy()
+    osum, ostat = oracle.run_batch(cfg, hb)
+    g_s, g_t = summ[:, pick], status[pick]
+    both = ((ostat & 0xFF) == _abi.END_GROUND) & ((g_t & 0xFF) == _abi.END_GROUND)
+    print(f"cfg-5 subset: oracle landed {np.mean((ostat & 0xFF) == _abi.END_GROUND):.3f}, fp32 agrees on {both.sum()} of 256")
+    assert both.mean() > 0.85            # the tumbling descent is chaotic: a few percent leave the fp64 solution
+    assert np.array_equal((g_t[both] & _abi.ST_CHUTE) != 0, (ostat[both] & _abi.ST_CHUTE) != 0)
+    assert np.max(relerr(g_s[_abi.SUM_APOGEE_ALT][both], osum[_abi.SUM_APOGEE_ALT][both])) < 1e-3
+    assert np.mean(relerr(g_s[_abi.SUM_FIRST_APOGEE_ALT], osum[_abi.SUM_FIRST_APOGEE_ALT]) <= 1e-3) >= 0.97
+    assert np.median(relerr(g_s[_abi.SUM_FLIGHT_TIME][both], osum[_abi.SUM_FLIGHT_TIME][both])) < 1e-2
+    assert np.array_equal(g_s[_abi.SUM_RAIL_EXIT_TIME], osum[_abi.SUM_RAIL_EXIT_TIME])
+    eng.close()
+
+
+_RANK_CODE = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import torch
+import torch.distributed as td
+td.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+import erpl_monte_carlo_sim_amd as E
+import helpers as H
+mc = E.MonteCarloAnalyzer(E.Rocket(), E.LiquidMotor(), E.StandardAtmosphere(), E.WindModel(), device="cuda:0", verbose=False)
+mc.base_altitude_profile, mc.base_wind_profile = H.CSV_ALT, H.CSV_WIND
+mc.n_trajectories = 3
+calls = []
+import erpl_monte_carlo_sim_amd.flatten as F
+orig = F.dispersed_batch
+def counting(*a, **k):
+    hb = orig(*a, **k)
+    calls.append(hb.n)
+    return hb
+F.dispersed_batch = counting
+n = int(os.environ["ERPL_TEST_N"])
+params = mc._generate_parameter_samples(n)
+summ, status, traj, lo = mc.run_batch_arrays(dict(H.EXAMPLE_IC), params)
+np.savez(os.environ["ERPL_TEST_OUT"] + f".{td.get_rank()}.npz", summ=summ, status=status, calls=np.array(calls), lo=lo,
+         n_traj=0 if traj is None else len(traj[0]))
+td.barrier()
+td.destroy_process_group()
+"""
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("n", [37, 2])
+def test_two_ranks_with_the_gpu_engine(tmp_path, n):
+    """The N > 1 path end to end with the real engine: two FRESH processes (started before anything here
+    touches the GPU in them), both on cuda:0, gloo backend, each building only its own shard on the host and
+    integrating it with the HIP kernels through MonteCarloAnalyzer.run_batch_arrays -> dist.run_local_shard;
+    the gathered [16, n] block must equal a single-process GPU run bit for bit on both ranks.  (RCCL itself
+    needs one GPU per rank and is exercised only by the driver's multi-GPU bench.)"""
+    out = str(tmp_path / "res")
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2",
+                   ERPL_TEST_N=str(n), ERPL_TEST_OUT=out, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", _RANK_CODE % {"root": ROOT}], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-3000:]
+    import erpl_monte_carlo_sim_amd as E
+    mc = E.MonteCarloAnalyzer(E.Rocket(), E.LiquidMotor(), E.StandardAtmosphere(), E.WindModel(), verbose=False)
+    mc.base_altitude_profile, mc.base_wind_profile = H.CSV_ALT, H.CSV_WIND
+    mc.n_trajectories = 3
+    ref_s, ref_t, _, _ = mc.run_batch_arrays(dict(H.EXAMPLE_IC), mc._generate_parameter_samples(n))
+    per = -(-n // 2)
+    for r in range(2):
+        z = np.load(out + f".{r}.npz")
+        assert np.array_equal(z["summ"], ref_s, equal_nan=True), r
+        assert np.array_equal(z["status"], ref_t), r
+        # host preparation is proportional to n / world: exactly one dispersed_batch call, of the shard's size
+        assert list(z["calls"]) == [per if r == 0 else n - per], (r, z["calls"])
+        assert int(z["lo"]) == r * per
+        assert int(z["n_traj"]) == (min(3, per) if r == 0 else max(0, min(3, n) - per))

@@ -1,0 +1,188 @@
+"""Known-answer tests ON THE DEVICE: tests/golden/kat.json (values captured from the imported Python
+reference) evaluated through erpl_mc_debug_eval, i.e. through the very device functions each kernel
+build inlines into its RK4 loop - atmosphere on both sides of every layer edge (environment.py:26-103),
+aerodynamic coefficients incl. stall and supersonic points (rocket.py:138-218), the 56 RHS cases incl. the
+latched parachute (simulator.py:295-460) - plus randomised RHS states against the CPU oracle.
+
+Tolerances per family (relative unless noted; fp32 values are what the hardware transcendental
+instructions and the documented floor-instead-of-dead-zone deviation deliver, measured then rounded up):
+                       f64 (gate)   f64_fast    f32
+  atmosphere T,P,rho,g   2e-13       5e-13       3e-6
+  aero coefficients      5e-13       2e-12       2e-5 (abs 2e-6)
+  RHS derivative rows    2e-12       2e-10       3e-4 of the largest entry of the block
+"""
+import numpy as np
+import pytest
+import torch
+
+from erpl_monte_carlo_sim_amd import _abi, flatten, models
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f64": {"atm": 2e-13, "aero": 5e-13, "rhs": 2e-12},
+       "f64_fast": {"atm": 5e-13, "aero": 2e-12, "rhs": 2e-10},
+       "f32": {"atm": 3e-6, "aero": 2e-5, "rhs": 3e-4}}
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from erpl_monte_carlo_sim_amd.engine import TrajectoryEngine
+    eng = TrajectoryEngine(torch.device("cuda", 0))
+    yield eng
+    eng.close()
+
+
+@pytest.fixture(scope="module")
+def kat():
+    return H.load_json("kat.json")
+
+
+def one_sample_batch(engine, kind, precision, wind=None):
+    from erpl_monte_carlo_sim_amd.engine import DeviceBatch
+    k = 0 if wind is None else len(wind["altitude"])
+    hb = flatten.HostBatch(1, k)
+    if k:
+        hb.alt_grid[:] = wind["altitude"]
+        hb.wind[:, :, 0] = np.array(wind["wind"])
+    r = models.Rocket()
+    hb.rocket[:, 0] = [r.dry_mass, r.propellant_mass]
+    hb.motor[:, 0] = flatten.motor_row(H.make_motor(kind))
+    hb.ic[6, 0] = 1.0
+    engine.set_config(H.make_config(kind))
+    return DeviceBatch.from_host(hb, engine.device, _abi.PRECISIONS[precision])
+
+
+@pytest.mark.parametrize("precision", ["f64", "f64_fast", "f32"])
+def test_atmosphere_kats_on_device(engine, kat, precision):
+    rows = np.array(kat["atmosphere"])
+    # both sides of every layer edge are in the fixture (11 / 20 / 25 / 32 km); add the exact edges
+    h = np.concatenate([rows[:, 0], [11000.0, 20000.0, 25000.0, 32000.0]])
+    db = one_sample_batch(engine, "liquid", precision)
+    got = engine.debug_eval(db, _abi.DBG_ATMOSPHERE, h[None, :])
+    exp = rows[:, [1, 2, 3, 5]].T                 # T, P, rho, g
+    if precision == "f32":                         # an fp32 altitude cannot tell 25 000.000001 m from 25 000 m:
+        keep = np.float32(rows[:, 0]).astype(np.float64) == rows[:, 0]      # keep the altitudes fp32 holds exactly
+    else:
+        keep = np.ones(len(rows), dtype=bool)
+    err = np.abs(got[:, :len(rows)] - exp) / np.abs(exp)
+    print(f"{precision}: atmosphere worst rel err {err[:, keep].max():.2e} over {keep.sum()} altitudes")
+    assert err[:, keep].max() < TOL[precision]["atm"]
+    assert keep.sum() >= 40
+    # layer edges belong to the LOWER layer (h <= edge), discontinuities kept
+    edge = got[:, len(rows):]
+    assert 2480.0 < edge[1, 2] < 2495.0 and 4790.0 < edge[1, 3] < 4815.0
+    lo = dict(zip(rows[:, 0], rows[:, 2]))
+    assert abs(edge[1, 2] - lo[25000.0]) / lo[25000.0] < max(TOL[precision]["atm"], 1e-12)
+
+
+@pytest.mark.parametrize("precision", ["f64", "f64_fast", "f32"])
+def test_aero_kats_on_device(engine, kat, precision):
+    rows = np.array(kat["aero"])
+    if precision != "f64":      # the fast RHS takes power_on = (pf > 0), as simulator.py:381 always passes it
+        rows = rows[(rows[:, 4] > 0) == (rows[:, 3] > 0)]
+        assert len(rows) >= 30
+    db = one_sample_batch(engine, "liquid", precision)
+    got = engine.debug_eval(db, _abi.DBG_AERO, rows[:, :5].T)
+    exp = rows[:, 5:10].T
+    tol = TOL[precision]["aero"]
+    err = np.abs(got - exp) / np.maximum(np.abs(exp), 0.1)
+    print(f"{precision}: aero worst err {err.max():.2e} over {rows.shape[0]} points "
+          f"(stall points: {(np.abs(rows[:, 1]) > np.radians(15)).sum()}, supersonic: {(rows[:, 0] > 1).sum()})")
+    assert err.max() < tol
+    assert (np.abs(rows[:, 1]) > np.radians(15)).sum() >= 5 and (rows[:, 0] > 1).sum() >= 5
+
+
+def rhs_inputs(cases):
+    x = np.zeros((16, len(cases)))
+    for j, c in enumerate(cases):
+        x[0, j] = c["t"]
+        x[1:15, j] = c["state"]
+        x[15, j] = c["chute_before"]
+    return x
+
+
+def block_err(got, exp):
+    """Worst error of each physical block (velocity, acceleration, q-dot, omega-dot, pf-dot) relative to the
+    largest reference entry of the block."""
+    worst = 0.0
+    for lo, hi in ((0, 3), (3, 6), (6, 10), (10, 13), (13, 14)):
+        scale = np.maximum(np.max(np.abs(exp[lo:hi]), axis=0), 1e-12)
+        worst = max(worst, float(np.max(np.abs(got[lo:hi] - exp[lo:hi]) / scale)))
+    return worst
+
+
+@pytest.mark.parametrize("precision", ["f64", "f64_fast", "f32"])
+def test_rhs_kats_on_device(engine, kat, precision):
+    w = kat["wind_csv"]
+    worst, n_chute = 0.0, 0
+    for kind in ("liquid", "solid"):
+        for has_wind in (0, 1):
+            cases = [c for c in kat["rhs"] if c["motor"] == kind and int(bool(c["wind"])) == has_wind]
+            if not cases:
+                continue
+            db = one_sample_batch(engine, kind, precision, w if has_wind else None)
+            got = engine.debug_eval(db, _abi.DBG_RHS, rhs_inputs(cases))
+            exp = np.array([c["deriv"] for c in cases]).T
+            assert np.array_equal(got[14], np.array([c["chute_after"] for c in cases], dtype=float)), (kind, has_wind)
+            n_chute += sum(c["chute_after"] for c in cases)
+            worst = max(worst, block_err(got[:14], exp))
+    print(f"{precision}: RHS KAT worst block error {worst:.2e} (latched-parachute cases: {n_chute})")
+    assert worst < TOL[precision]["rhs"]
+    assert n_chute >= 10
+
+
+@pytest.mark.parametrize("precision", ["f64", "f64_fast", "f32"])
+def test_rhs_random_states_vs_oracle(engine, oracle, precision):
+    """600 random states against the CPU oracle: altitudes -50 m ... 60 km (all five atmosphere layers, the
+    mesosphere one is otherwise reached only by diverged flights), Mach 0 ... 5, angles of attack through
+    the stall model, burning and burnt out, parachute latched or about to latch; plus the corner the fp32
+    build documents as a deviation: relative speeds below the 1e-6 m/s dead zone of utils.py:160-172."""
+    rs = np.random.RandomState(7)
+    w = H.load_json("kat.json")["wind_csv"]
+    n = 600
+    for kind in ("liquid", "solid"):
+        cfg = H.make_config(kind)
+        db = one_sample_batch(engine, kind, precision, w)
+        hb = flatten.HostBatch(1, len(w["altitude"]))
+        hb.alt_grid[:] = w["altitude"]
+        hb.wind[:, :, 0] = np.array(w["wind"])
+        r = models.Rocket()
+        hb.rocket[:, 0] = [r.dry_mass, r.propellant_mass]
+        hb.motor[:, 0] = flatten.motor_row(H.make_motor(kind))
+        x = np.zeros((16, n))
+        x[0] = rs.uniform(0.0, 40.0, n)
+        x[1:3] = rs.normal(0, 500.0, (2, n))
+        x[3] = np.where(rs.rand(n) < 0.15, rs.uniform(-50.0, 520.0, n), rs.uniform(0.0, 60000.0, n))
+        speed = rs.uniform(0.0, 1500.0, n)
+        q = rs.normal(size=(4, n))
+        q /= np.linalg.norm(q, axis=0)
+        # velocity mostly along body-x (small angles), a third of the cases tumbling (any direction)
+        from_body = np.zeros((3, n))
+        a, b = rs.normal(0, 0.15, n), rs.normal(0, 0.1, n)
+        wide = rs.rand(n) < 0.33
+        a[wide], b[wide] = rs.uniform(-1.4, 1.4, wide.sum()), rs.uniform(-1.0, 1.0, wide.sum())
+        from_body[0], from_body[1], from_body[2] = np.cos(a) * np.cos(b), np.sin(b), np.sin(a) * np.cos(b)
+        qw, qx, qy, qz = q
+        R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy)],
+                      [2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx)],
+                      [2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)]])
+        x[4:7] = np.einsum("ijn,jn->in", R, from_body) * speed
+        x[7:11] = q
+        x[11:14] = rs.normal(0, 0.3, (3, n))
+        x[14] = np.where(rs.rand(n) < 0.3, 0.0, rs.uniform(0.0, 1.0, n))
+        x[15] = rs.rand(n) < 0.1
+        x[4:7, :12] = rs.normal(0, 3e-7, (3, 12))    # dead-zone corner: |v_rel| ~ 1e-7 m/s in still air ...
+        x[3, :12] = 30000.0                           # ... above the wind table's last knot (15, 3, 0) -> subtract it
+        x[4, :12] += 15.0
+        x[5, :12] += 3.0
+        got = engine.debug_eval(db, _abi.DBG_RHS, x)
+        exp = np.zeros((15, n))
+        for j in range(n):
+            d, chute = oracle.rhs(cfg, hb, x[0, j], x[1:15, j], int(x[15, j]))
+            exp[:14, j], exp[14, j] = d, chute
+        assert np.array_equal(got[14], exp[14]), kind
+        err = block_err(got[:14], exp[:14])
+        print(f"{precision}/{kind}: random-state RHS worst block error {err:.2e}")
+        assert err < 5 * TOL[precision]["rhs"], kind

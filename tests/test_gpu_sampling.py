@@ -1,0 +1,172 @@
+"""SURVEY 8f-2 / 8f-3 on the device: the on-device dispersion + wind synthesis (sampling.synthetic_dispersions,
+erpl_mc_synth_wind) against the bit-exact host generator (flatten.dispersed_batch, pinned to inputs captured
+inside the reference), and the on-device outlier filter + statistics against the reference's own
+_analyze_results numbers (tests/golden/stats.json)."""
+import numpy as np
+import pytest
+import torch
+from scipy import stats as sps
+
+from erpl_monte_carlo_sim_amd import _abi, analysis, flatten, models, sampling
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+N = 24000
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from erpl_monte_carlo_sim_amd.engine import TrajectoryEngine
+    eng = TrajectoryEngine(torch.device("cuda", 0))
+    eng.set_config(H.make_config("liquid"))
+    yield eng
+    eng.close()
+
+
+def host_rows(kind, csv):
+    pl = flatten.generate_parameter_arrays(H.UNCERTAINTY, N)
+    kw = dict(base_altitude_profile=H.CSV_ALT, base_wind_profile=H.CSV_WIND) if csv else {}
+    return flatten.dispersed_batch(models.Rocket(), H.make_motor(kind), models.WindModel(), H.EXAMPLE_IC, pl, **kw)
+
+
+def device_rows(engine, kind, csv, precision=_abi.PREC_F64, seed=4242):
+    kw = dict(base_altitude_profile=H.CSV_ALT, base_wind_profile=H.CSV_WIND) if csv else {}
+    db = sampling.synthetic_dispersions(N, models.Rocket(), H.make_motor(kind), models.WindModel(), H.EXAMPLE_IC,
+                                        engine.device, precision=precision, seed=seed, engine=engine, **kw)
+    torch.cuda.synchronize()
+    return db
+
+
+def check_column(name, dev, host):
+    """Same distribution: two-sample KS (alpha 1e-4 per column), mean within 5 standard errors, std within 4 %."""
+    dev, host = np.asarray(dev, dtype=np.float64), np.asarray(host, dtype=np.float64)
+    sd = host.std()
+    if sd == 0.0:
+        assert dev.std() == 0.0 and dev.mean() == host.mean(), name
+        return
+    se = sd * np.sqrt(2.0 / len(host))
+    assert abs(dev.mean() - host.mean()) < 5 * se, (name, dev.mean(), host.mean())
+    assert abs(dev.std() / sd - 1.0) < 0.04, (name, dev.std(), sd)
+    p = sps.ks_2samp(dev, host).pvalue
+    assert p > 1e-4, (name, p)
+
+
+@pytest.mark.parametrize("kind,csv", [("liquid", False), ("liquid", True), ("solid", False), ("solid", True)])
+def test_synthetic_dispersions_match_host_generator_in_distribution(engine, kind, csv):
+    hb = host_rows(kind, csv)
+    db = device_rows(engine, kind, csv)
+    assert db.k_wind == hb.k_wind and np.array_equal(db.alt_grid.cpu().numpy(), hb.alt_grid)
+    ic, rk, mt, wind = (t.cpu().numpy() for t in (db.ic, db.rocket, db.motor, db.wind))
+    for r in range(13):
+        check_column(f"ic[{r}]", ic[r], hb.ic[r])
+    for r in range(2):
+        check_column(f"rocket[{r}]", rk[r], hb.rocket[r])
+    for r in range(4):
+        check_column(f"motor[{r}]", mt[r], hb.motor[r])
+    K = hb.k_wind
+    for k in sorted(set([0, 1, 2, 4, K // 2, K - 1])):
+        for c in range(3):
+            check_column(f"wind[{k},{c}]", wind[k, c], hb.wind[k, c])
+    # AR(1) structure: knot-to-knot correlation of the turbulence (mean wind removed by differencing u against
+    # its own sample mean is not enough for the offset/power-law part, so compare like with like)
+    for k in (1, K // 2, K - 1):
+        for c in (0, 2):
+            a = np.corrcoef(wind[k - 1, c], wind[k, c])[0, 1]
+            b = np.corrcoef(hb.wind[k - 1, c], hb.wind[k, c])[0, 1]
+            assert abs(a - b) < 0.03, (k, c, a, b)
+
+
+@pytest.mark.parametrize("kind", ["liquid", "solid"])
+def test_shared_draws_of_the_three_same_seed_streams(engine, kind):
+    """monte_carlo.py:274/:287/:323: dispersions, motor and wind are drawn from three streams with the SAME
+    seed, so their leading normals coincide: the thrust multiplier's normal is also the first position
+    normal (sigma 0) and the u-turbulence of knot 0; the velocity-offset normals are the turbulence of
+    knot 1; attitude <-> knot 2; angular velocity <-> knot 3; mass <-> u of knot 4.  The device generator
+    reproduces that joint law."""
+    hb = host_rows(kind, True)
+    db = device_rows(engine, kind, True)
+    ic, rk, mt, wind = (t.cpu().numpy() for t in (db.ic, db.rocket, db.motor, db.wind))
+
+    def pairs(icx, rkx, mtx, wx):
+        # remove the per-sample uniform offset from knot-0 turbulence by differencing against the w-free mean:
+        # u(0) = base + speed*cos(dir) + sigma0*z0 -> correlate with the thrust row directly (offset is independent)
+        return {
+            "thrust~u0": np.corrcoef(mtx[0], wx[0, 0])[0, 1],
+            "vel_x~u1": np.corrcoef(icx[3], wx[1, 0])[0, 1],
+            "vel_z~w1": np.corrcoef(icx[5], wx[1, 2])[0, 1],
+            "omega_y~v3": np.corrcoef(icx[11], wx[3, 1])[0, 1],
+            "mass~u4": np.corrcoef(rkx[0], wx[4, 0])[0, 1],
+            "thrust~w0 (independent)": np.corrcoef(mtx[0], wx[0, 2])[0, 1],
+        }
+    h, d = pairs(hb.ic, hb.rocket, hb.motor, hb.wind), pairs(ic, rk, mt, wind)
+    print({k: (round(h[k], 3), round(d[k], 3)) for k in h})
+    for k in h:
+        assert abs(h[k] - d[k]) < 0.03, (k, h[k], d[k])
+    assert h["thrust~u0"] > 0.5 and h["vel_z~w1"] > 0.2       # the coupling is really there in the reference
+    if kind == "liquid":   # mass-flow multiplier <-> v-turbulence of knot 0
+        a = np.corrcoef(hb.motor[2] / hb.rocket[1], hb.wind[0, 1])[0, 1]
+        b = np.corrcoef(mt[2] / rk[1], wind[0, 1])[0, 1]
+        assert abs(a - b) < 0.03 and abs(a) > 0.3, (a, b)
+
+
+def test_fp32_tables_are_the_rounded_fp64_tables(engine):
+    """The AR(1) recursion runs in fp64 whatever the batch precision: the fp32 table is the rounding of the
+    fp64 one (same seed), not an fp32 recursion."""
+    a = device_rows(engine, "liquid", False, _abi.PREC_F64, seed=9)
+    b = device_rows(engine, "liquid", False, _abi.PREC_F32, seed=9)
+    assert b.wind.dtype == torch.float32 and a.wind.dtype == torch.float64
+    assert torch.equal(a.wind.float(), b.wind)
+    assert torch.equal(a.ic, b.ic) and torch.equal(a.motor, b.motor)
+
+
+def test_generation_is_a_single_digit_percentage_of_a_pass(engine):
+    """generation must stay below 5 % of the integration of the same batch."""
+    import time
+    n = 131072
+    rocket, motor, wm = models.Rocket(), models.LiquidMotor(), models.WindModel()
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        db = sampling.synthetic_dispersions(n, rocket, motor, wm, H.EXAMPLE_IC, engine.device, precision=_abi.PREC_F32,
+                                            seed=1, engine=engine)
+        torch.cuda.synchronize()
+        gen = time.perf_counter() - t0
+    engine.run(db)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    engine.run(db)
+    torch.cuda.synchronize()
+    run = time.perf_counter() - t0
+    print(f"generate {gen * 1e3:.2f} ms, integrate {run * 1e3:.2f} ms ({100 * gen / run:.1f} %)")
+    assert gen < 0.25 * run     # wall clock incl. torch launch overheads; the device time is ~1 ms
+
+
+def test_generated_batches_obey_the_input_contract(engine):
+    wm = models.WindModel()
+    with pytest.raises(_abi.ErplError, match="input contract"):
+        sampling.synthetic_dispersions(512, models.Rocket(), models.LiquidMotor(), wm, H.EXAMPLE_IC, engine.device,
+                                       uncertainty={"mass_uncertainty": 5.0}, engine=engine)   # negative masses
+
+
+# ------------------------------------------------------------------ f-3: device statistics on the device
+def test_device_statistics_equal_the_reference_on_device_tensors(engine):
+    """analysis.device_statistics on CUDA tensors holding the inputs of tests/golden/stats.json ==
+    the reference's _analyze_results numbers (monte_carlo.py:337-459), incl. NaN / inf / outlier rows."""
+    g = H.load_json("stats.json")
+    inp = g["inputs"]
+    keep = [i for i in range(len(inp["apogee_altitude"])) if i != inp["none_index"]]   # a failed sample is not in the tensors
+    summ = torch.zeros((16, len(keep)), dtype=torch.float64)
+    summ[_abi.SUM_APOGEE_ALT] = torch.tensor([inp["apogee_altitude"][i] for i in keep], dtype=torch.float64)
+    summ[_abi.SUM_RANGE] = torch.tensor([inp["range"][i] for i in keep], dtype=torch.float64)
+    summ[_abi.SUM_FLIGHT_TIME] = torch.tensor([inp["flight_time"][i] for i in keep], dtype=torch.float64)
+    status = torch.zeros((len(keep),), dtype=torch.int32)
+    out = analysis.device_statistics(summ.to(engine.device), status.to(engine.device))
+    assert out["n_samples"] == g["n_samples"] and out["n_outliers"] == g["n_outliers"]
+    for key in ("apogee_altitude", "range", "flight_time"):
+        for stat in ("mean", "std", "min", "max"):
+            assert out[key][stat] == pytest.approx(g[key][stat], rel=1e-12), (key, stat)
+        assert np.allclose(out[key]["percentiles"], g[key]["percentiles"], rtol=1e-12)
+    a = np.array([inp["apogee_altitude"][i] for i in keep])
+    assert (~np.isfinite(a)).sum() >= 2      # the fixture really carries NaN / inf rows
