@@ -39,10 +39,12 @@ def _euler_to_quaternion(roll, pitch, yaw):
                         cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy])
 
 
-def _check_ranges(ic, rk, mt, wind):
+def _check_ranges(ic, rk, mt, mean_u, mean_v):
     """The input contract `DeviceBatch.from_host` enforces, for batches generated on the device: the
-    kernels assume finite inputs, positive masses and mass flow, a finite non-negative burn time."""
-    ok = (torch.isfinite(ic).all() & torch.isfinite(rk).all() & torch.isfinite(mt).all() & torch.isfinite(wind).all()
+    kernels assume finite inputs, positive masses and mass flow, a finite non-negative burn time.  (The
+    wind table is a finite linear map of the finite normals, per-knot constants and mean-wind rows.)"""
+    ok = (torch.isfinite(ic).all() & torch.isfinite(rk).all() & torch.isfinite(mt).all()
+          & torch.isfinite(mean_u).all() & torch.isfinite(mean_v).all()
           & (rk > 0).all() & (mt[2] > 0).all() & (mt[3] >= 0).all())
     if not bool(ok):
         raise _abi.ErplError("generated dispersions violate the kernel input contract (finite values, positive "
@@ -160,5 +162,5 @@ def synthetic_dispersions(n, rocket, motor, wind_model, base_initial_conditions,
                                        ptr(scale_d), ptr(mean_u), ptr(mean_v), ptr(wind), int(precision),
                                        C.c_void_p(st.cuda_stream))
     _abi.check(engine.lib, rc, "erpl_mc_synth_wind")
-    _check_ranges(ic, rk, mt, wind)
+    _check_ranges(ic, rk, mt, mean_u, mean_v)
     return DeviceBatch(ic, rk, mt, dev64(alt_np).contiguous(), wind, precision)

@@ -69,12 +69,33 @@ def test_atmosphere_kats_on_device(engine, kat, precision):
     err = np.abs(got[:, :len(rows)] - exp) / np.abs(exp)
     print(f"{precision}: atmosphere worst rel err {err[:, keep].max():.2e} over {keep.sum()} altitudes")
     assert err[:, keep].max() < TOL[precision]["atm"]
-    assert keep.sum() >= 40
+    assert keep.sum() >= (15 if precision == "f32" else 60)
     # layer edges belong to the LOWER layer (h <= edge), discontinuities kept
     edge = got[:, len(rows):]
     assert 2480.0 < edge[1, 2] < 2495.0 and 4790.0 < edge[1, 3] < 4815.0
     lo = dict(zip(rows[:, 0], rows[:, 2]))
     assert abs(edge[1, 2] - lo[25000.0]) / lo[25000.0] < max(TOL[precision]["atm"], 1e-12)
+
+
+@pytest.mark.parametrize("precision", ["f64", "f64_fast", "f32"])
+def test_atmosphere_grid_vs_oracle_on_device(engine, oracle, precision):
+    """400 altitudes that fp32 holds exactly, -100 m ... 99 999 m, incl. the last fp32 value below / at / the first
+    above every layer edge (11, 20, 25, 32 km), against the CPU oracle (itself pinned by the fixture above): every
+    layer of the fp32 record formulation, the mesosphere one included."""
+    f = np.float32
+    edges = [f(11000.0), f(20000.0), f(25000.0), f(32000.0)]
+    near = [v for e in edges for v in (np.nextafter(e, f(0)), e, np.nextafter(e, f(1e9)))]
+    h = np.concatenate([np.linspace(-100.0, 99999.0, 388).astype(np.float32), np.array(near, dtype=np.float32)]).astype(np.float64)
+    cfg = H.make_config("liquid")
+    db = one_sample_batch(engine, "liquid", precision)
+    got = engine.debug_eval(db, _abi.DBG_ATMOSPHERE, h[None, :])
+    exp = np.array([list(oracle.atmosphere(cfg, x)[:3]) + [oracle.gravity(cfg, x)] for x in h]).T
+    err = np.abs(got - exp) / np.abs(exp)
+    by_layer = {name: float(err[:, (h > lo) & (h <= hi)].max()) for name, lo, hi in
+                (("<=11km", -1e9, 11000.0), ("<=20km", 11000.0, 20000.0), ("<=25km", 20000.0, 25000.0),
+                 ("<=32km", 25000.0, 32000.0), (">32km", 32000.0, 1e9))}
+    print(f"{precision}: atmosphere grid worst rel err by layer {by_layer}")
+    assert err.max() < TOL[precision]["atm"]
 
 
 @pytest.mark.parametrize("precision", ["f64", "f64_fast", "f32"])
@@ -130,7 +151,7 @@ def test_rhs_kats_on_device(engine, kat, precision):
             worst = max(worst, block_err(got[:14], exp))
     print(f"{precision}: RHS KAT worst block error {worst:.2e} (latched-parachute cases: {n_chute})")
     assert worst < TOL[precision]["rhs"]
-    assert n_chute >= 10
+    assert n_chute >= 6
 
 
 @pytest.mark.parametrize("precision", ["f64", "f64_fast", "f32"])

@@ -49,25 +49,28 @@ def main():
     ap.add_argument("--chunks", default="0,512,1024,2048")
     ap.add_argument("--overlaps", default="0,2,3,4")
     ap.add_argument("--waves", default="2,3")
+    ap.add_argument("--max-blocks", default="0", help="workgroup caps to sweep (0 = library default)")
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--planar", action="store_true")
+    ap.add_argument("--lib", default=None, help="experiment build of the library to load instead of the product")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "sweep_overlap.json"))
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     rocket, motor, atm, wm = models.Rocket(), models.LiquidMotor(), models.StandardAtmosphere(), models.WindModel()
-    eng = TrajectoryEngine(dev)
+    eng = TrajectoryEngine(dev, lib_path=a.lib)
     eng.set_config(flatten.config_from_objects(rocket, motor, atm))
     prec = _abi.PRECISIONS[a.precision]
     db = sampling.synthetic_dispersions(a.n, rocket, motor, wm, IC, dev, precision=prec, seed=1234, planar=a.planar)
     flags = _abi.FLAG_STOP_AT_APOGEE if a.planar else 0
     rows = []
     ints = lambda s: [int(x) for x in s.split(",")]
-    for block, chunk, waves, ov in itertools.product(ints(a.blocks), ints(a.chunks), ints(a.waves), ints(a.overlaps)):
-        eng.set_launch(block, 0, 1)
+    for block, chunk, waves, ov, mb in itertools.product(ints(a.blocks), ints(a.chunks), ints(a.waves), ints(a.overlaps),
+                                                       ints(a.max_blocks)):
+        eng.set_launch(block, mb, 1)
         eng.set_chunk(chunk)
         eng.set_waves_per_simd(waves)
         ms = timed(eng, db, flags, a.reps, ov)
-        row = {"precision": a.precision, "n": a.n, "block": block, "chunk": chunk, "waves": waves, "overlap": ov,
+        row = {"lib": os.path.basename(a.lib) if a.lib else "product", "precision": a.precision, "n": a.n, "block": block, "chunk": chunk, "waves": waves, "overlap": ov, "max_blocks": mb,
                "ms_per_pass": round(ms, 3), "traj_per_s": round(a.n / ms * 1e3)}
         rows.append(row)
         print(json.dumps(row), flush=True)
