@@ -366,8 +366,19 @@ def main():
         out["cpu_baseline"] = None   # measured by the N = 1 run only (the host cores are shared by the ranks)
     if rank == 0 and world == 1 and not args.no_parity:
         # the fp64 reference-order gate kernel on the SAME shard: the per-sample reference for every timed build
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record()
         gs, gt = eng.run(as_precision(db64, _abi.PREC_F64), flags=flags)
+        g1.record()
         torch.cuda.synchronize()
+        gate_ms = g0.elapsed_time(g1)
+        gate_steps, _ = eng.last_stats()
+        gate_tf = gate_steps * FLOPS_PER_STEP / (gate_ms * 1e-3) / 1e12
+        out["f64_gate"] = {"note": "the fp64 reference-order kernel (ERPL_PREC_F64), ONE pass over the same shard, alone on the GPU",
+                           "ms": gate_ms, "value": n / gate_ms * 1e3, "unit": "trajectories/s",
+                           "roofline": {"bound": "valu", "achieved": gate_tf, "peak": PEAK_TFLOPS["f64"], "unit": "TFLOP/s",
+                                        "frac": gate_tf / PEAK_TFLOPS["f64"], "kernel": "erpl_flight_f64",
+                                        "rk4_steps_per_launch": gate_steps}}
         gs, gt = gs.cpu().numpy(), gt.cpu().numpy()
         rep = match_report(gs, gt, main_leg["summary"].cpu().numpy(), main_leg["status"].cpu().numpy())
         out["apogee_match_rate"] = rep["apogee_match_rate_0p1pct"]
@@ -426,6 +437,18 @@ def main():
                 res[name] = r
             out["parity"]["cfg2_set_r_1k_vs_cpu_oracle"] = res
             eng.set_config(cfg)
+    if rank == 0 and world == 1 and not args.no_parity and args.workload == "set_s":
+        # the named API end to end (generate on the device + integrate + statistics), outside the timed region
+        import erpl_monte_carlo_sim_amd as E
+        mc = E.MonteCarloAnalyzer(rocket, motor, atm, wm, device=device, verbose=False)
+        api = {}
+        for precision in ("f64_fast", "f32"):
+            mc.run_monte_carlo_device(dict(EXAMPLE_IC), n, precision=precision)      # warm-up (allocations, first launches)
+            r = mc.run_monte_carlo_device(dict(EXAMPLE_IC), n, precision=precision)
+            api[precision] = {k: r["performance"][k] for k in ("simulations_per_second", "total_time", "generate_s",
+                                                               "integrate_and_gather_s", "statistics_s")}
+            api[precision]["n_valid"], api[precision]["n_outliers"] = r["n_samples"], r["n_outliers"]
+        out["api_end_to_end"] = {"call": f"MonteCarloAnalyzer.run_monte_carlo_device(ic, {n}, precision=...)", **api}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -327,14 +327,7 @@ def generate_parameter_samples(uncertainty, n_samples, stream="seed_i"):
     per-sample dicts, bit-identical to the reference's values."""
     if stream == "seed_42":   # one sequential stream: nothing to spread over samples
         return generate_parameter_samples_loop(uncertainty, n_samples, stream)
-    a = generate_parameter_arrays(uncertainty, n_samples)
-    out = []
-    for i in range(n_samples):
-        d = {k: a[k][i].copy() for k in _VEC_KEYS}
-        d.update({k: float(a[k][i]) for k in _SCALAR_KEYS})
-        d["random_seed"] = i
-        out.append(d)
-    return out
+    return _arrays_to_params(generate_parameter_arrays(uncertainty, n_samples))
 
 
 def params_to_arrays(params_list):
@@ -483,11 +476,22 @@ def dispersed_batch(rocket, motor, wind_model, base_initial_conditions, params_l
 
 
 def _arrays_to_params(P):
+    """Dict of arrays -> the reference's list of per-sample dicts (3-vectors as float64 arrays, scalars as
+    Python floats).  Built from column lists: the rows of each 3-vector are views into ONE private copy of its
+    [n, 3] array (no per-sample allocation - at 1e5 samples the per-sample `.copy()` + `float()` form spent
+    140 us per sample, most of it in the cyclic garbage collector walking the growing list of dicts)."""
+    import gc
     n = len(P["random_seed"])
-    out = []
-    for i in range(n):
-        d = {k: P[k][i].copy() for k in _VEC_KEYS}
-        d.update({k: float(P[k][i]) for k in _SCALAR_KEYS if k in P})
-        d["random_seed"] = int(P["random_seed"][i])
-        out.append(d)
+    keys = list(_VEC_KEYS) + [k for k in _SCALAR_KEYS if k in P] + ["random_seed"]
+    cols = [list(np.array(P[k], dtype=np.float64)) for k in _VEC_KEYS]
+    cols += [np.asarray(P[k], dtype=np.float64).tolist() for k in _SCALAR_KEYS if k in P]
+    cols.append(np.asarray(P["random_seed"]).astype(np.int64).tolist())
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        out = [dict(zip(keys, row)) for row in zip(*cols)]
+    finally:
+        if was_enabled:
+            gc.enable()
+    assert len(out) == n
     return out

@@ -140,9 +140,12 @@ class MonteCarloAnalyzer:
         if self.verbose:
             print(f"Running Monte Carlo analysis with {n_samples} samples...")
         t0 = time.time()
-        params = (self._generate_parameter_samples_vectorized(n_samples) if optimized
-                  else self._generate_parameter_samples(n_samples))
-        summ, status, traj, lo = self.run_batch_arrays(initial_conditions, params)
+        if optimized:   # one sequential RandomState(42) stream (monte_carlo.py:181-201): a list by construction
+            params = batch_params = self._generate_parameter_samples_vectorized(n_samples)
+        else:           # per-sample RandomState(i) streams: keep the array form for the batch construction
+            batch_params = flatten.generate_parameter_arrays(self.uncertainty_params, n_samples)
+            params = flatten._arrays_to_params(batch_params)
+        summ, status, traj, lo = self.run_batch_arrays(initial_conditions, batch_params)
         results = self._result_dicts(summ, status, params, traj, lo)
         if self.verbose:
             print(f"Completed {len(results)} out of {n_samples} simulations")
