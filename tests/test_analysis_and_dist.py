@@ -149,6 +149,55 @@ def _worker(rank, world, port, n, q):
     td.destroy_process_group()
 
 
+def _worker_local(rank, world, port, n, q):
+    """Each rank builds ONLY its own shard on the host (per-sample seeds) and hands it to run_local_shard."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    lo, hi, _ = dist.shard_bounds(n, rank, world)
+    arr = flatten.generate_parameter_arrays(H.UNCERTAINTY, n)
+    mine = {k: v[lo:hi] for k, v in arr.items()}
+    hb = flatten.dispersed_batch(models.Rocket(), models.LiquidMotor(), models.WindModel(), H.EXAMPLE_IC, mine,
+                                 H.CSV_ALT, H.CSV_WIND) if hi > lo else None
+    cfg = H.make_config("liquid")
+
+    def runner(shard):
+        s, t = orc.run_batch(cfg, shard, threads=1)
+        return torch.from_numpy(s), torch.from_numpy(t)
+
+    summ, status = dist.run_local_shard(n, hb, runner)
+    q.put((rank, 0 if hb is None else hb.n, summ, status))
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [7, 1])
+def test_two_rank_gloo_local_shards(n):
+    """Host preparation proportional to n / world: every rank builds only samples [lo, hi) (an EMPTY shard on
+    rank 1 when n = 1) and the gathered result equals the single-process batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_local, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=180) for _ in procs], key=lambda o: o[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    from oracle import oracle as orc
+    pl = flatten.generate_parameter_samples(H.UNCERTAINTY, n)
+    hb = flatten.dispersed_batch(models.Rocket(), models.LiquidMotor(), models.WindModel(), H.EXAMPLE_IC, pl,
+                                 H.CSV_ALT, H.CSV_WIND)
+    ref_s, ref_t = orc.run_batch(H.make_config("liquid"), hb, threads=2)
+    per = -(-n // 2)
+    assert [o[1] for o in outs] == [per, n - per]
+    for rank, _, summ, status in outs:
+        assert np.array_equal(summ, ref_s, equal_nan=True), rank
+        assert np.array_equal(status, ref_t), rank
+
+
 @pytest.mark.parametrize("n", [9, 2])
 def test_two_rank_gloo_shard_and_gather(n):
     """N > 1 path: each rank integrates only its shard; after the all-gather every rank holds the

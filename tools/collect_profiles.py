@@ -35,7 +35,7 @@ line = json.loads(open(os.path.join(go, f"{tag}_bench.json")).read().strip().spl
 json.dump(line, open(os.path.join(prof, f"{pre}_bench_line_final.json"), "w"), indent=1)
 extra = {}
 keys = ("value", "ms_per_step", "dtype", "trajectory_steps_per_s", "lane_utilisation", "roofline")
-for w in ("set_p_apogee", "set_p_apogee_gate", "set_p_full", "csv_chute", "set_s_1m", "cfg5_share"):
+for w in ("set_p_apogee", "set_p_apogee_gate", "set_p_full", "csv_chute", "set_s_1m", "cfg5_share", "cfg5_share_compaction"):
     p = os.path.join(go, f"{tag}_bench_{w}.json")
     if os.path.exists(p) and os.path.getsize(p):
         d = json.loads(open(p).read().strip().splitlines()[-1])

@@ -19,4 +19,5 @@ python3 bench.py --workload set_p_apogee --steps 2 --warmup 1 --cpu-seconds 0 --
 python3 bench.py --workload set_p_full --steps 3 --warmup 1 --cpu-seconds 0 --no-parity > gpurun_out/${tag}_bench_set_p_full.json 2>/dev/null &&
 python3 bench.py --workload csv_chute --steps 3 --warmup 1 --cpu-seconds 0 --no-parity > gpurun_out/${tag}_bench_csv_chute.json 2>/dev/null &&
 python3 bench.py --samples-per-gpu 1048576 --steps 4 --warmup 2 --cpu-seconds 0 --no-parity > gpurun_out/${tag}_bench_set_s_1m.json 2>/dev/null &&
-python3 bench.py --workload csv_chute --samples-per-gpu 1250000 --steps 2 --warmup 1 --cpu-seconds 0 --no-parity > gpurun_out/${tag}_bench_cfg5_share.json 2>/dev/null
+python3 bench.py --workload csv_chute --samples-per-gpu 1250000 --steps 2 --warmup 1 --cpu-seconds 0 --no-parity > gpurun_out/${tag}_bench_cfg5_share.json 2>/dev/null &&
+python3 bench.py --workload csv_chute --samples-per-gpu 1250000 --chunk 2048 --overlap 2 --steps 2 --warmup 1 --cpu-seconds 0 --no-parity > gpurun_out/${tag}_bench_cfg5_share_compaction.json 2>/dev/null
