@@ -227,7 +227,6 @@ struct erpl_ctx {
   int last_slot = 0;              // slot of the most recent batch (erpl_mc_last_stats)
   int64_t reserve_n = 0;          // erpl_mc_reserve request, applied to a slot when it is first used
   int chunk = 0;
-  int block_sync = 0;   // in-kernel workgroup compaction period in RK4 iterations (0 = off)
   int waves = 0;   // 0 = choose by batch size
   // one wave per workgroup: a finished wave frees its slot for the next batch at once (measured 2-5 %
   // over 256-thread workgroups, alone and overlapped); refill as soon as a lane is idle (best: 1..4)
@@ -252,9 +251,7 @@ int slot_reserve(ErplSlot& s, int64_t n) {
   if (n <= s.cap) return ERPL_OK;
   if (s.used) HIP_TRY(hipEventSynchronize(s.done));
   slot_free_workspace(s);
-  // + one workgroup of slack: the in-kernel compaction addresses the spare buffer by workgroup slice
-  // (blockIdx * blockDim + k), and the last workgroup of a ragged batch reaches past n
-  const size_t rows = (size_t)n + 1024;
+  const size_t rows = (size_t)n;
   for (int k = 0; k < 2; ++k) {
     HIP_TRY(hipMalloc(&s.res_r[k], rows * ERPL_RES_R * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&s.res_d[k], rows * ERPL_RES_D * sizeof(double)));
@@ -326,7 +323,7 @@ int enqueue_batch(erpl_ctx* c, int si, const erpl_batch* b, const erpl_out* o, h
   fill_common_args(c, b, a);
   a.summary = o->summary; a.status = o->status;
   for (int k = 0; k < 2; ++k) { a.res_r[k] = s.res_r[k]; a.res_d[k] = s.res_d[k]; a.res_i[k] = s.res_i[k]; }
-  a.res_cap = s.cap + 1024;   // rows allocated (slot_reserve)
+  a.res_cap = s.cap;
   a.qcnt = s.d_queue; a.qhead = s.d_queue + (ERPL_MAX_PHASES + 2);
   a.n_traj = o->n_traj; a.traj_stride = o->traj_stride; a.traj_cap = o->traj_cap;
   a.traj_ids = o->traj_ids; a.traj = o->traj; a.traj_len = o->traj_len;
@@ -351,7 +348,6 @@ int enqueue_batch(erpl_ctx* c, int si, const erpl_batch* b, const erpl_out* o, h
     a.chunk_steps = (int)chunk;
     n_phases = (int)ceil(max_steps / chunk) + 1;
   }
-  a.block_sync_steps = (a.chunk_steps == 0 && o->n_traj == 0 && c->block > 64) ? c->block_sync : 0;
   void** ev = c->profiling ? (void**)&c->ev[3 * (c->profiled_runs % ERPL_PROFILE_RING)] : nullptr;
   int lrc;
   if (b->precision == ERPL_PREC_F64) lrc = erpl_launch_f64(a, &T.s64, c->block, max_blocks, n_phases, st, ev);
@@ -439,12 +435,6 @@ int erpl_mc_reserve(erpl_ctx* c, int64_t n) {
 int erpl_mc_set_chunk(erpl_ctx* c, int chunk_steps) {
   if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
   c->chunk = chunk_steps < 0 ? 0 : chunk_steps;
-  return ERPL_OK;
-}
-
-int erpl_mc_set_block_compaction(erpl_ctx* c, int steps) {
-  if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
-  c->block_sync = steps < 0 ? 0 : steps;
   return ERPL_OK;
 }
 

@@ -98,7 +98,6 @@ struct ErplKArgs {
   int32_t phase;               // index of this flight launch
   int32_t chunk_steps;         // RK4 steps a lane may take per launch (<= 0: unlimited, one launch)
   int32_t waves_per_simd;      // fp32 flight-kernel build to launch: 2 (256 VGPRs) or 3 (168 VGPRs, spills)
-  int32_t block_sync_steps;    // in-kernel workgroup compaction every this many RK4 iterations (<= 0: off)
   // trajectory capture
   int64_t n_traj, traj_stride, traj_cap;
   const int64_t* traj_ids;

@@ -102,10 +102,6 @@ class TrajectoryEngine:
         """Step-chunked launches with per-GPU compaction in between (0 = single launch)."""
         _abi.check(self.lib, self.lib.erpl_mc_set_chunk(self._ctx, int(chunk_steps)), "erpl_mc_set_chunk")
 
-    def set_block_compaction(self, steps):
-        """In-kernel workgroup compaction every `steps` RK4 iterations (erpl_mc_set_block_compaction; 0 = off)."""
-        _abi.check(self.lib, self.lib.erpl_mc_set_block_compaction(self._ctx, int(steps)), "erpl_mc_set_block_compaction")
-
     def reserve(self, n):
         _abi.check(self.lib, self.lib.erpl_mc_reserve(self._ctx, n), "erpl_mc_reserve")
 

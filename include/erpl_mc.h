@@ -218,13 +218,6 @@ int erpl_mc_set_waves_per_simd(erpl_ctx* ctx, int waves);
  * do not depend on the value (bitwise). */
 int erpl_mc_set_chunk(erpl_ctx* ctx, int chunk_steps);
 
-/* In-kernel workgroup compaction: every `steps` RK4 iterations the waves of a workgroup (set_launch: 128 or 256
- * threads) meet at a barrier, and whenever their flying trajectories fit into fewer waves than are still alive
- * they are re-packed densely and the emptied waves end (their SIMD slots go to waiting workgroups / overlapped
- * batches).  No launch boundary and no device-wide barrier, unlike erpl_mc_set_chunk (with which it is mutually
- * exclusive: chunking wins).  0 = off.  Results do not depend on the value (bitwise). */
-int erpl_mc_set_block_compaction(erpl_ctx* ctx, int steps);
-
 /* Diagnostics of the last run_batch on this ctx (after the stream has been synchronised):
  * total RK4 steps integrated over all samples and total wave-iterations executed. */
 int erpl_mc_last_stats(erpl_ctx* ctx, double* total_steps, double* wave_iterations);

@@ -229,32 +229,3 @@ def test_fp32_set_r_rates_are_what_design_md_states(engine, oracle):
     assert 0.15 <= ap <= 0.25
     assert fa >= 0.98
     assert 0.50 <= end <= 0.60
-
-
-@pytest.mark.parametrize("precision", ["f32", "f64_fast"])
-def test_workgroup_compaction_is_bitwise_neutral(engine, precision):
-    """erpl_mc_set_block_compaction: the waves of a workgroup re-pack their flying lanes at in-kernel barriers.
-    Which lane integrates which sample changes, the numbers must not - for ragged sizes, both workgroup sizes
-    that have more than one wave, frequent and rare meetings, alone and with batches overlapped."""
-    prec = _abi.PRECISIONS[precision]
-    engine.set_config(H.make_config("liquid"))
-    rocket, motor, wm = models.Rocket(), models.LiquidMotor(), models.WindModel()
-    db = sampling.synthetic_dispersions(9001, rocket, motor, wm, H.EXAMPLE_IC, engine.device, precision=prec, seed=21, engine=engine)
-    ref_s, ref_t = (x.clone() for x in engine.run(db))
-    _, wi0 = engine.last_stats()
-    try:
-        for block, sync in ((256, 16), (128, 100), (256, 700)):
-            engine.set_launch(block, 0, 1)
-            engine.set_block_compaction(sync)
-            s, t = engine.run(db)
-            steps, wi = engine.last_stats()
-            assert torch.equal(t, ref_t) and same(s, ref_s), (block, sync)
-            assert wi < wi0, (block, sync, wi, wi0)          # fewer wave iterations: lanes really were re-packed
-            outs = [engine.submit(db) for _ in range(4)]
-            engine.wait()
-            torch.cuda.synchronize()
-            for s2, t2 in outs:
-                assert torch.equal(t2, ref_t) and same(s2, ref_s), (block, sync)
-    finally:
-        engine.set_launch(64, 0, 1)
-        engine.set_block_compaction(0)
