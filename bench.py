@@ -449,6 +449,19 @@ def main():
                                                                "integrate_and_gather_s", "statistics_s")}
             api[precision]["n_valid"], api[precision]["n_outliers"] = r["n_samples"], r["n_outliers"]
         out["api_end_to_end"] = {"call": f"MonteCarloAnalyzer.run_monte_carlo_device(ic, {n}, precision=...)", **api}
+        # the reference-exact drop-in: per-sample MT19937 streams on the host, list-of-dicts results (monte_carlo.py:52-90)
+        m_host = 20000
+        for precision in ("f64_fast", "f64"):
+            mc.precision = precision
+            t1 = time.perf_counter()
+            try:
+                res = mc.run_monte_carlo(dict(EXAMPLE_IC), n_samples=m_host)
+                shape = {"n_valid": res["n_samples"], "n_outliers": res["n_outliers"]}
+            except ValueError as e:      # the reference's own behaviour when no sample survives the outlier rules
+                shape = {"raised": str(e)[:60]}
+            el = time.perf_counter() - t1
+            out["api_end_to_end"]["run_monte_carlo_" + precision] = {"n_samples": m_host, "total_time": el,
+                                                                    "simulations_per_second": m_host / el, **shape}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

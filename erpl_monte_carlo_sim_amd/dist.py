@@ -26,11 +26,12 @@ def shard_bounds(n, rank, world_size):
     return lo, hi, per
 
 
-def all_gather_summaries(summary, status, n_total, group=None):
+def all_gather_summaries(summary, status, n_total, group=None, force_collective=False):
     """summary [S, n_local], status [n_local] of this rank -> ([S, n_total], [n_total]) on every
-    rank.  Tensors stay on their device (GPU for nccl/RCCL, CPU for gloo)."""
+    rank.  Tensors stay on their device (GPU for nccl/RCCL, CPU for gloo).  A single-rank world returns
+    its inputs unless `force_collective` (tests: run the collective itself in a one-rank RCCL group)."""
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 and not (force_collective and torch.distributed.is_available() and torch.distributed.is_initialized()):
         return summary, status
     d = torch.distributed
     _, _, per = shard_bounds(n_total, rank, ws)

@@ -186,3 +186,40 @@ def test_two_ranks_with_the_gpu_engine(tmp_path, n):
         assert list(z["calls"]) == [per if r == 0 else n - per], (r, z["calls"])
         assert int(z["lo"]) == r * per
         assert int(z["n_traj"]) == (min(3, per) if r == 0 else max(0, min(3, n) - per))
+
+
+_RCCL_CODE = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import torch
+import torch.distributed as td
+torch.cuda.set_device(0)
+td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+import erpl_monte_carlo_sim_amd as E
+from erpl_monte_carlo_sim_amd import dist, _abi
+import helpers as H
+mc = E.MonteCarloAnalyzer(E.Rocket(), E.LiquidMotor(), E.StandardAtmosphere(), E.WindModel(), device="cuda:0", verbose=False)
+mc.n_trajectories = 0
+out = mc.run_monte_carlo_device(dict(H.EXAMPLE_IC), 5000, planar=True)       # ws == 1: no collective inside
+summ, status = out["summary"], out["status"]
+assert summ.is_cuda and status.is_cuda
+g_s, g_t = dist.all_gather_summaries(summ, status, 5000, force_collective=True)   # RCCL all_gather_into_tensor on device buffers
+torch.cuda.synchronize()
+assert g_s.is_cuda and torch.equal(g_t, status) and bool(((g_s == summ) | (g_s.isnan() & summ.isnan())).all())
+print("rccl-ok", td.get_backend(), tuple(g_s.shape))
+td.destroy_process_group()
+"""
+
+
+def test_rccl_one_rank_group_runs_the_gather_on_device_buffers():
+    """RCCL needs one GPU per rank, so on a one-GPU box only a ONE-rank "nccl" group can run: it still loads
+    RCCL, creates the communicator on the device and pushes the [16, n] / [n] device tensors of a real run
+    through all_gather_into_tensor - the collective `dist.all_gather_summaries` issues at N > 1."""
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_CODE % {"root": ROOT}], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "rccl-ok nccl (16, 5000)" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
