@@ -18,7 +18,7 @@ ap.add_argument("--waves", type=int, default=0)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 rocket, motor, atm, wm = models.Rocket(), models.LiquidMotor(), models.StandardAtmosphere(), models.WindModel()
-eng = TrajectoryEngine(dev); eng.set_config(flatten.config_from_objects(rocket, motor, atm))
+eng = TrajectoryEngine(dev, lib_path=os.environ.get("ERPL_LIB")); eng.set_config(flatten.config_from_objects(rocket, motor, atm))
 prec = _abi.PRECISIONS[a.precision]
 kw = dict(base_altitude_profile=B.CSV_ALT, base_wind_profile=B.CSV_WIND) if a.wind == "csv" else {}
 db = sampling.synthetic_dispersions(a.n, rocket, motor, wm, B.EXAMPLE_IC, dev, precision=prec, seed=1234, planar=a.planar, **kw)
