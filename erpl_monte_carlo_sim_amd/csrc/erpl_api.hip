@@ -317,8 +317,7 @@ int enqueue_batch(erpl_ctx* c, int si, const erpl_batch* b, const erpl_out* o, h
   if (rc != ERPL_OK) return rc;
   // the slot's previous batch (possibly on another stream) must have drained its queues
   if (s.used) HIP_TRY(hipStreamWaitEvent(st, s.done, 0));
-  HIP_TRY(hipMemsetAsync(s.d_counters, 0, 16 * sizeof(unsigned long long), st));
-  HIP_TRY(hipMemsetAsync(s.d_queue, 0, 2 * (ERPL_MAX_PHASES + 2) * sizeof(unsigned long long), st));
+  // (queue cursors and counters are zeroed by the rail kernel itself)
   ErplKArgs a;
   fill_common_args(c, b, a);
   a.summary = o->summary; a.status = o->status;
