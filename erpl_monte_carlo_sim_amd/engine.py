@@ -99,7 +99,8 @@ class TrajectoryEngine:
         _abi.check(self.lib, self.lib.erpl_mc_set_waves_per_simd(self._ctx, int(waves)), "erpl_mc_set_waves_per_simd")
 
     def set_chunk(self, chunk_steps):
-        """Step-chunked launches with per-GPU compaction in between (0 = single launch)."""
+        """Step-chunked launches with per-GPU compaction in between (0 = single launch; < 0 = the library decides
+        per batch from the trajectory lengths of the batches it has finished: erpl_mc_set_chunk)."""
         _abi.check(self.lib, self.lib.erpl_mc_set_chunk(self._ctx, int(chunk_steps)), "erpl_mc_set_chunk")
 
     def reserve(self, n):

@@ -214,8 +214,10 @@ int erpl_mc_set_waves_per_simd(erpl_ctx* ctx, int waves);
 
 /* Per-GPU compaction (BASELINE config 5): integrate in launches of `chunk_steps` RK4 steps; lanes
  * that are still flying at the end of a chunk park their state densely in a resume queue and the
- * next launch continues them with fully populated waves.  0 = one launch, no compaction.  Results
- * do not depend on the value (bitwise). */
+ * next launch continues them with fully populated waves.  0 = one launch, no compaction; < 0 (the default) =
+ * chosen per batch: 2048 for batches submitted with erpl_mc_submit_batch once the batches this context has
+ * finished averaged >= 8192 RK4 steps per trajectory (there another batch fills every chunk barrier: -17...-20 %
+ * time on 15 k - 42 k-step flights), otherwise one launch.  Results do not depend on the value (bitwise). */
 int erpl_mc_set_chunk(erpl_ctx* ctx, int chunk_steps);
 
 /* Diagnostics of the last run_batch on this ctx (after the stream has been synchronised):

@@ -268,3 +268,35 @@ def test_f64_fast_without_wind_table_and_with_trajectory_capture(engine, oracle,
     k = int(tlen[0])
     hist = engine.extract_histories(db, ids[0], torch.as_tensor(traj[0, :k], device=engine.device), float(s1[_abi.SUM_RAIL_EXIT_TIME, ids[0]].item()))
     assert hist.shape == (k, _abi.DIAG_DIM) and bool(torch.isfinite(hist).all())
+
+
+def test_automatic_step_chunks_follow_the_trajectory_length():
+    """Default erpl_mc_set_chunk (< 0): batches submitted for overlap are step-chunked with compaction once the
+    batches the context has FINISHED averaged >= 8192 RK4 steps per trajectory.  Same bits either way; the
+    device counters show when the compaction is on (fewer wave iterations for the same physics steps)."""
+    from erpl_monte_carlo_sim_amd.engine import TrajectoryEngine
+    eng = TrajectoryEngine(torch.device("cuda", 0))          # fresh context: no history, default settings
+    try:
+        eng.set_config(H.make_config("liquid"))
+        rocket, motor, wm = models.Rocket(), models.LiquidMotor(), models.WindModel()
+        util = {}
+        for name, planar, flags in (("long", True, _abi.FLAG_STOP_AT_APOGEE), ("short", False, 0)):
+            db = sampling.synthetic_dispersions(20000, rocket, motor, wm, H.EXAMPLE_IC, eng.device, precision=_abi.PREC_F32,
+                                                seed=3, planar=planar, engine=eng)
+            ref_s, ref_t = (x.clone() for x in eng.run(db, flags=flags))      # run_batch: always one launch
+            steps0, wi0 = eng.last_stats()
+            assert (steps0 / db.n >= 8192) == (name == "long")
+            u = []
+            for _ in range(3):                                                   # history builds up batch by batch
+                s, t = eng.submit(db, flags=flags)
+                eng.wait()
+                steps, wi = eng.last_stats()
+                assert torch.equal(t, ref_t) and same(s, ref_s)
+                assert steps == steps0
+                u.append(steps / 64.0 / wi)
+            util[name] = (steps0 / 64.0 / wi0, u)
+        print("lane utilisation, run_batch vs three submits:", util)
+        assert util["long"][1][-1] > util["long"][0] + 0.02         # long flights: compaction switched on ...
+        assert abs(util["short"][1][-1] - util["short"][0]) < 0.02   # ... and off again after batches of short ones
+    finally:
+        eng.close()

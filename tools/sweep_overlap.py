@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--overlaps", default="0,2,3,4")
     ap.add_argument("--waves", default="2,3")
     ap.add_argument("--max-blocks", default="0", help="workgroup caps to sweep (0 = library default)")
+    ap.add_argument("--check", action="store_true", help="compare every point's results with the first point's, bit for bit")
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--planar", action="store_true")
     ap.add_argument("--lib", default=None, help="experiment build of the library to load instead of the product")
@@ -64,13 +65,22 @@ def main():
     flags = _abi.FLAG_STOP_AT_APOGEE if a.planar else 0
     rows = []
     ints = lambda s: [int(x) for x in s.split(",")]
+    ref = None
     for block, chunk, waves, ov, mb in itertools.product(ints(a.blocks), ints(a.chunks), ints(a.waves), ints(a.overlaps),
                                                        ints(a.max_blocks)):
         eng.set_launch(block, mb, 1)
         eng.set_chunk(chunk)
         eng.set_waves_per_simd(waves)
         ms = timed(eng, db, flags, a.reps, ov)
-        row = {"lib": os.path.basename(a.lib) if a.lib else "product", "precision": a.precision, "n": a.n, "block": block, "chunk": chunk, "waves": waves, "overlap": ov, "max_blocks": mb,
+        same = None
+        if a.check:
+            s_, t_ = eng.run(db, flags=flags)
+            torch.cuda.synchronize()
+            if ref is None:
+                ref = (s_.clone(), t_.clone())
+            same = bool(torch.equal(t_, ref[1]) and ((s_ == ref[0]) | (s_.isnan() & ref[0].isnan())).all())
+        steps, wi = eng.last_stats()
+        row = {"bitwise_equal_to_first": same, "util": round(steps / 64 / wi, 3) if wi else None,"lib": os.path.basename(a.lib) if a.lib else "product", "precision": a.precision, "n": a.n, "block": block, "chunk": chunk, "waves": waves, "overlap": ov, "max_blocks": mb,
                "ms_per_pass": round(ms, 3), "traj_per_s": round(a.n / ms * 1e3)}
         rows.append(row)
         print(json.dumps(row), flush=True)
