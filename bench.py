@@ -39,8 +39,10 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # one hardware queue per batch in flight (include/erpl_mc.h), before HIP starts
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -142,6 +144,7 @@ def main():
     ap.add_argument("--block", type=int, default=0, help="threads per workgroup (0 = library default)")
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--refill", type=int, default=1)
+    ap.add_argument("--adopt", type=int, default=-1, help="lane adoption limit (erpl_mc_set_adopt); 0 = off; -1 = library default")
     ap.add_argument("--overlap", type=int, default=-1, help="passes in flight (erpl_mc_set_overlap); 0 = erpl_mc_run_batch on the stream; -1 = library default")
     ap.add_argument("--waves", type=int, default=0, help="fp32 kernel build: 2 or 3 waves per SIMD (0 = library default)")
     ap.add_argument("--chunk", type=int, default=-1, help="steps per launch between compactions (-1 = library default)")
@@ -180,9 +183,19 @@ def main():
     if args.chunk >= 0:
         eng.set_chunk(args.chunk)
     eng.set_waves_per_simd(args.waves)
-    if args.overlap > 0:
-        eng.set_overlap(args.overlap)
-    depth = args.overlap if args.overlap >= 0 else 3
+    if args.adopt >= 0:
+        eng.set_adopt(args.adopt)
+    lib_depth = eng.get_overlap()     # 8 when the process has a hardware queue per batch in flight, else 3
+
+    def leg_depth(precision):
+        """Passes in flight for a leg.  All K passes finish inside the timed region, so the pipeline's fill and
+        drain count: at the driver's K = 20 the fp32 kernel is fastest six deep (steady state: eight), the
+        one-wave-per-SIMD fp64 kernels eight deep (measured)."""
+        if args.overlap >= 0:
+            return args.overlap
+        return min(lib_depth, 6) if precision == "f32" else lib_depth
+
+    depth = leg_depth(args.precision)
     n = args.samples_per_gpu
     planar = args.workload.startswith("set_p")
     flags = _abi.FLAG_STOP_AT_APOGEE if args.workload == "set_p_apogee" else 0
@@ -198,6 +211,9 @@ def main():
         """W warm-up + K timed passes of one kernel build; returns the measurements of this rank."""
         prec = _abi.PRECISIONS[precision]
         db = as_precision(db64, prec)
+        depth = leg_depth(precision)
+        if depth > 0:
+            eng.set_overlap(depth)
         nbuf = max(depth, 1) + (1 if world > 1 else 0)
         outs = [eng.alloc_outputs(n) for _ in range(nbuf)]
         gath = []
@@ -282,7 +298,7 @@ def main():
             tot = torch.tensor([phys_steps], dtype=torch.float64, device="cpu" if gloo_rehearsal else device)
             dist.all_reduce(tot)
             phys_total = float(tot.item())
-        return {"precision": precision, "prec": prec, "db": db, "elapsed": elapsed, "gpu_ms": gpu_ms,
+        return {"precision": precision, "prec": prec, "db": db, "elapsed": elapsed, "gpu_ms": gpu_ms, "depth": depth,
                 "summary": summary, "status": status, "rail_ms": rail_ms, "flight_ms": flight_ms,
                 "phys_steps": phys_steps, "wave_iters": wave_iters, "phys_total": phys_total}
 
@@ -319,7 +335,7 @@ def main():
                             (("max_time", 0), ("ground", 1), ("altitude_100km", 2), ("coast", 3), ("apogee", 4))},
             "nan_fraction": float(np.mean((st & _abi.ST_NAN) != 0)),
             "kernel_ms": {"gpu_ms_per_launch": per_launch_ms, "erpl_flight_dispatch_mean": fl, "erpl_rail_dispatch_mean": rl,
-                          "launches_in_flight": max(depth, 1),
+                          "launches_in_flight": max(L["depth"], 1),
                           "per_dispatch_flight_ms": [round(x, 3) for x in L["flight_ms"]]},
             "roofline": {
                 "bound": "valu", "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tf / peak,
@@ -354,7 +370,8 @@ def main():
                                     f"{'CSV base wind K=6' if csv else 'synthetic wind K=100'}, "
                                     f"rail dt=0.01 + RK4 dt=0.005, "
                                     f"{'to first-descent apogee' if flags else 'full reference termination logic'}",
-                        "samples_per_gpu": n, "precision": args.precision, "passes_in_flight": max(depth, 1),
+                        "samples_per_gpu": n, "precision": args.precision, "passes_in_flight": max(depth, 1), "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                        "lane_adoption": "library default" if args.adopt < 0 else args.adopt,
                         "parallelism": f"sample-shard x{world}" + (" + RCCL all-gather of [16,n] summaries overlapped with the following passes" if world > 1 else ""),
                     }})
         out.update(body)

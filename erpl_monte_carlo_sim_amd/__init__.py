@@ -1,6 +1,12 @@
 """MI355X-native Monte Carlo 6-DOF trajectory engine (drop-in for the hot path of
 smcconoughey/erpl_monte_carlo_sim: MonteCarloAnalyzer.run_monte_carlo / FlightSimulator.simulate_flight).
 """
+import os as _os
+
+# Eight batches in flight need a hardware queue each (include/erpl_mc.h, erpl_mc_set_overlap); the HIP
+# runtime reads the limit once, at its first call - which a bare `import torch` has not made yet.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 from .models import Rocket, SolidMotor, LiquidMotor, StandardAtmosphere, WindModel  # noqa: F401
 
 __version__ = "0.1.0"

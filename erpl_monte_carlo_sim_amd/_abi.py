@@ -94,7 +94,7 @@ EXPORTS = ("erpl_mc_abi_version", "erpl_mc_last_error", "erpl_mc_create", "erpl_
            "erpl_mc_kernel_ms_history", "erpl_mc_debug_counters", "erpl_mc_extract_histories", "erpl_mc_set_chunk",
            "erpl_mc_legacy_random_streams", "erpl_mc_legacy_wind_profiles", "erpl_mc_set_waves_per_simd",
            "erpl_mc_set_overlap", "erpl_mc_submit_batch", "erpl_mc_wait_batch", "erpl_mc_synchronize",
-           "erpl_mc_debug_eval", "erpl_mc_synth_wind")
+           "erpl_mc_debug_eval", "erpl_mc_synth_wind", "erpl_mc_set_adopt", "erpl_mc_get_overlap")
 
 _lib = None
 
@@ -138,6 +138,9 @@ def load_library(path=None):
     lib.erpl_mc_debug_eval.argtypes = [C.c_void_p, C.POINTER(ErplBatch), C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_void_p]
     lib.erpl_mc_set_chunk.argtypes = [C.c_void_p, C.c_int]
+    lib.erpl_mc_set_adopt.argtypes = [C.c_void_p, C.c_int]
+    lib.erpl_mc_get_overlap.argtypes = [C.c_void_p]
+    lib.erpl_mc_get_overlap.restype = C.c_int
     lib.erpl_mc_set_waves_per_simd.argtypes = [C.c_void_p, C.c_int]
     lib.erpl_mc_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.erpl_mc_set_profiling.argtypes = [C.c_void_p, C.c_int]

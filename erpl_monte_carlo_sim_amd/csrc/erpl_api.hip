@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -199,6 +200,21 @@ int build_tables(const erpl_config& c, ErplTables& T) {
 }  // namespace
 
 // One workspace of the context: resume queues, queue cursors and counters of ONE batch in flight.
+// Hardware queues the HIP runtime multiplexes this process's streams onto: GPU_MAX_HW_QUEUES, read by the
+// runtime when it initialises (default 4).  Streams that share a queue run their kernels one after the
+// other, so more batches in flight than queues is slower than three (measured at 131 072 samples, fp32:
+// depth 4 / 4 queues 16.9 ms per batch, depth 4 / 8 queues 11.8 ms).  The library cannot ask the runtime;
+// it trusts the environment variable the host set before the first HIP call (the Python package does).
+static int hw_queues_env() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("GPU_MAX_HW_QUEUES");
+    const int q = e ? atoi(e) : 0;
+    v = q > 0 ? q : 4;
+  }
+  return v;
+}
+
 // Slot 0 serves erpl_mc_run_batch (on the caller's stream); slots 0..depth-1 serve erpl_mc_submit_batch
 // round-robin, each on its own internal stream.  Whoever uses a slot first waits (on the device) for
 // the slot's previous batch and records `done` behind its own kernels.
@@ -224,10 +240,11 @@ struct erpl_ctx {
   ErplTables h_tables;            // host copy (scalars are passed to the kernels by value)
   ErplTables* d_tables = nullptr;
   ErplSlot slot[ERPL_MAX_OVERLAP];
-  int depth = 3;                  // slots erpl_mc_submit_batch cycles through (measured best at 131 072 samples)
+  int depth = 3;                  // slots erpl_mc_submit_batch cycles through (erpl_mc_create: 8 with enough hardware queues)
   int64_t submitted = 0;          // tickets handed out
   int last_slot = 0;              // slot of the most recent batch (erpl_mc_last_stats)
   int64_t reserve_n = 0;          // erpl_mc_reserve request, applied to a slot when it is first used
+  int adopt = -1;                 // lane adoption: flying lanes at or below which a wave hands its lanes over; 0 = off; < 0 = by batch
   int chunk = -1;                 // steps per launch between compactions; 0 = one launch; < 0 = by the batches seen so far
   double seen_mean_steps = 0.0;   // physics RK4 steps per trajectory of the most recent COMPLETED batch
   int64_t seen_seq = 0, batches = 0;
@@ -371,6 +388,18 @@ int enqueue_batch(erpl_ctx* c, int si, const erpl_batch* b, const erpl_out* o, h
     a.chunk_steps = (int)chunk;
     n_phases = (int)ceil(max_steps / chunk) + 1;
   }
+  // lane adoption (erpl_mc_set_adopt): two sweep launches behind the main one fly out what no running wave
+  // adopted - the first parks its own thin waves once more, the last one never parks
+  // Automatic (erpl_mc_set_adopt < 0, the default): fp32 batches with at least five in flight on queues of their
+  // own.  There the GPU is short of issue slots, not of batches, and the 15-20 % fewer wave-iterations pay
+  // (131 072 samples, eight deep: 11.6 -> 10.3 ms); with three in flight the batch's own longest trajectory
+  // bounds it and the hand-overs only lengthen that (12.2 -> 15.1 ms).  The fp64 builds run one wave per SIMD
+  // and gain nothing (measured); step chunks already re-pack every lane, and chunk-parked records would be
+  // adopted straight back (measured 8x slower), so the two are exclusive.
+  int adopt = c->adopt;
+  if (adopt < 0) adopt = (b->precision == ERPL_PREC_F32 && in_flight >= 5 && hw_queues_env() >= in_flight + 2) ? 24 : 0;
+  a.adopt_lanes = (o->n_traj == 0 && a.chunk_steps == 0) ? adopt : 0;
+  if (a.adopt_lanes > 0 && n_phases < 3) n_phases = 3;
   void** ev = c->profiling ? (void**)&c->ev[3 * (c->profiled_runs % ERPL_PROFILE_RING)] : nullptr;
   int lrc;
   if (b->precision == ERPL_PREC_F64) lrc = erpl_launch_f64(a, &T.s64, c->block, max_blocks, n_phases, st, ev);
@@ -411,6 +440,7 @@ int erpl_mc_create(int device, erpl_ctx** out) {
   c->device = device;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+  c->depth = (hw_queues_env() >= ERPL_MAX_OVERLAP + 2) ? ERPL_MAX_OVERLAP : 3;   // + the caller's stream and one more of its own
   hipError_t e = hipMalloc((void**)&c->d_tables, sizeof(ErplTables));
   for (int i = 0; i < 3 * ERPL_PROFILE_RING && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
   if (e != hipSuccess) { (void)erpl_mc_destroy(c); return fail(ERPL_ERR_HIP, "hipMalloc/hipEventCreate: %s", hipGetErrorString(e)); }
@@ -471,6 +501,13 @@ int erpl_mc_set_waves_per_simd(erpl_ctx* c, int waves) {
   return ERPL_OK;
 }
 
+int erpl_mc_set_adopt(erpl_ctx* c, int lanes) {
+  if (!c) return fail(ERPL_ERR_INVALID, "null context");
+  if (lanes > 63) return fail(ERPL_ERR_INVALID, "adopt lanes must be at most 63");
+  c->adopt = lanes < 0 ? -1 : lanes;
+  return ERPL_OK;
+}
+
 int erpl_mc_set_launch(erpl_ctx* c, int block_threads, int max_blocks, int refill_threshold) {
   if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
   if (block_threads != 64 && block_threads != 128 && block_threads != 256)
@@ -488,6 +525,8 @@ int erpl_mc_run_batch(erpl_ctx* c, const erpl_batch* b, const erpl_out* o, void*
   HIP_TRY(hipSetDevice(c->device));
   return enqueue_batch(c, 0, b, o, (hipStream_t)stream, 1);
 }
+
+int erpl_mc_get_overlap(erpl_ctx* c) { return c ? c->depth : 0; }
 
 int erpl_mc_set_overlap(erpl_ctx* c, int depth) {
   if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
@@ -537,7 +576,12 @@ int erpl_mc_wait_batch(erpl_ctx* c, int64_t ticket, void* stream) {
 int erpl_mc_synchronize(erpl_ctx* c) {
   if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
   HIP_TRY(hipSetDevice(c->device));
-  return wait_all_host(c);
+  const int rc = wait_all_host(c);
+  if (rc != ERPL_OK) return rc;
+  for (int i = 0; i < ERPL_MAX_OVERLAP; ++i)   // counters of every finished batch sit in pinned memory
+    if (c->slot[i].used && c->slot[i].h_counters[3] != 0ull)
+      return fail(ERPL_ERR_HIP, "lane hand-over timed out in batch %lld: its results are incomplete", (long long)c->slot[i].ticket);
+  return ERPL_OK;
 }
 
 int erpl_mc_set_profiling(erpl_ctx* c, int enable) {
@@ -832,6 +876,7 @@ int erpl_mc_last_stats(erpl_ctx* c, double* total_steps, double* wave_iterations
   HIP_TRY(hipMemcpy(h, ls.d_counters, sizeof(h), hipMemcpyDeviceToHost));
   if (total_steps) *total_steps = (double)h[1];
   if (wave_iterations) *wave_iterations = (double)h[2];
+  if (h[3] != 0ull) return fail(ERPL_ERR_HIP, "lane hand-over timed out: the results of the last batch are incomplete");
   return ERPL_OK;
 }
 

@@ -13,7 +13,7 @@
 #define ERPL_ATM_REC 12          // aT bT Tlo Thi invTref eL href eH eM base (2 pad)
 #define ERPL_RES_R 20
 #define ERPL_RES_D 5
-#define ERPL_RES_I 5
+#define ERPL_RES_I 6
 #define ERPL_MAX_PHASES 2048
 #define ERPL_COAST_TABLE 2048   // rail-iteration counts covered by the NaN fast-forward table
 
@@ -91,13 +91,17 @@ struct ErplKArgs {
   void* res_r[2];              // [ERPL_RES_R][res_cap] working precision: y[14], apogee, first_apogee,
                                //   max_speed2, max_coast, cx, cy
   double* res_d[2];            // [ERPL_RES_D][res_cap]: t, t_rail, apogee_t, first_apogee_t, latch_t
-  int32_t* res_i[2];           // [ERPL_RES_I][res_cap]: id, steps, nrail, mode|flags, traj_len
+  int32_t* res_i[2];           // [ERPL_RES_I][res_cap]: id, steps, nrail, mode|flags, traj_len, ready (the phase
+                               //   that may pop the record, once it is published to running adopters)
   int64_t res_cap;
   unsigned long long* qcnt;    // [ERPL_MAX_PHASES + 2] records available to phase p (phase 0: n)
   unsigned long long* qhead;   // [ERPL_MAX_PHASES + 2] pop cursor of phase p
   int32_t phase;               // index of this flight launch
   int32_t chunk_steps;         // RK4 steps a lane may take per launch (<= 0: unlimited, one launch)
   int32_t waves_per_simd;      // fp32 flight-kernel build to launch: 2 (256 VGPRs) or 3 (168 VGPRs, spills)
+  int32_t adopt_lanes;         // > 0: a wave left with at most this many flying lanes once the queue is empty
+                               //   parks them in the next phase's queue, where waves that still fly more pick
+                               //   them up into their idle lanes (the launcher clears it for the last phase)
   // trajectory capture
   int64_t n_traj, traj_stride, traj_cap;
   const int64_t* traj_ids;

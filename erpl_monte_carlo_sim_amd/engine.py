@@ -103,6 +103,11 @@ class TrajectoryEngine:
         per batch from the trajectory lengths of the batches it has finished: erpl_mc_set_chunk)."""
         _abi.check(self.lib, self.lib.erpl_mc_set_chunk(self._ctx, int(chunk_steps)), "erpl_mc_set_chunk")
 
+    def set_adopt(self, lanes):
+        """Lane adoption: waves down to `lanes` flying trajectories hand them to fuller waves (0 = off, < 0 = the
+        library decides per batch: erpl_mc_set_adopt)."""
+        _abi.check(self.lib, self.lib.erpl_mc_set_adopt(self._ctx, int(lanes)), "erpl_mc_set_adopt")
+
     def reserve(self, n):
         _abi.check(self.lib, self.lib.erpl_mc_reserve(self._ctx, n), "erpl_mc_reserve")
 
@@ -111,8 +116,12 @@ class TrajectoryEngine:
         status = torch.empty((n,), dtype=torch.int32, device=self.device)
         return summary, status
 
+    def get_overlap(self):
+        """Batches `submit()` keeps in flight at once (3, or 8 when the process has the hardware queues for it)."""
+        return int(self.lib.erpl_mc_get_overlap(self._ctx))
+
     def set_overlap(self, depth):
-        """Batches `submit()` keeps in flight at once (erpl_mc_set_overlap; 1..8, library default 2)."""
+        """Batches `submit()` keeps in flight at once (erpl_mc_set_overlap; 1..8)."""
         _abi.check(self.lib, self.lib.erpl_mc_set_overlap(self._ctx, int(depth)), "erpl_mc_set_overlap")
 
     def submit(self, db, **kw):

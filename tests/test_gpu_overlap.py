@@ -278,6 +278,7 @@ def test_automatic_step_chunks_follow_the_trajectory_length():
     eng = TrajectoryEngine(torch.device("cuda", 0))          # fresh context: no history, default settings
     try:
         eng.set_config(H.make_config("liquid"))
+        eng.set_overlap(3)                                   # three deep: lane adoption (its own test) stays off
         rocket, motor, wm = models.Rocket(), models.LiquidMotor(), models.WindModel()
         util = {}
         for name, planar, flags in (("long", True, _abi.FLAG_STOP_AT_APOGEE), ("short", False, 0)):
@@ -298,5 +299,119 @@ def test_automatic_step_chunks_follow_the_trajectory_length():
         print("lane utilisation, run_batch vs three submits:", util)
         assert util["long"][1][-1] > util["long"][0] + 0.02         # long flights: compaction switched on ...
         assert abs(util["short"][1][-1] - util["short"][0]) < 0.02   # ... and off again after batches of short ones
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64_fast", "f64"])
+def test_lane_adoption_does_not_change_a_bit(engine, precision):
+    """erpl_mc_set_adopt: waves down to a few flying lanes hand them to fuller waves through the resume queue
+    (release / acquire at device scope inside one launch, two sweep launches behind it).  Every limit gives
+    the bits of the plain launch, alone and with eight batches in flight, with fewer wave iterations."""
+    prec = _abi.PRECISIONS[precision]
+    engine.set_config(H.make_config("liquid"))
+    n = 30000 if precision == "f32" else (12000 if precision == "f64_fast" else 4000)
+    rocket, motor, wm = models.Rocket(), models.LiquidMotor(), models.WindModel()
+    db = sampling.synthetic_dispersions(n, rocket, motor, wm, H.EXAMPLE_IC, engine.device, precision=prec, seed=77, engine=engine)
+    try:
+        engine.set_adopt(0)
+        engine.set_chunk(0)
+        ref_s, ref_t = (x.clone() for x in engine.run(db))
+        steps0, wi0 = engine.last_stats()
+        for lanes in (1, 8, 24, 63):
+            engine.set_adopt(lanes)
+            s, t = engine.run(db)
+            steps, wi = engine.last_stats()          # raises if a hand-over timed out
+            assert torch.equal(t, ref_t) and same(s, ref_s), lanes
+            assert steps == steps0
+            assert engine.debug_counters()[3] == 0
+            if lanes in (8, 24):   # (63: every wave parks at its first finished lane and nobody may adopt - the sweeps fly it all)
+                assert wi < wi0 * 0.97, (lanes, wi, wi0)   # the thin tails are gone
+        engine.set_adopt(24)
+        engine.set_overlap(8)
+        outs = [engine.submit(db) for _ in range(12)]
+        engine.wait()
+        engine.synchronize()
+        for s, t in outs:
+            assert torch.equal(t, ref_t) and same(s, ref_s)
+    finally:
+        engine.set_adopt(-1)
+        engine.set_chunk(-1)
+        engine.set_overlap(3)
+
+
+def test_lane_adoption_with_parachute_events_and_stop_at_apogee(engine):
+    """Adopted lanes carry their whole record: parachute flag, first-descent latch, NaN flag, rail data.  The
+    CSV-wind parachute set (BASELINE config 5's ingredients) and the to-apogee set, with every wave parking
+    (limit 63), against the plain launch (itself checked against the CPU oracle elsewhere in this file)."""
+    rocket, motor, wm = models.Rocket(), models.LiquidMotor(), models.WindModel()
+    engine.set_config(H.make_config("liquid"))
+    try:
+        for planar, flags, csv in ((True, _abi.FLAG_STOP_AT_APOGEE, False), (True, 0, True)):
+            db = sampling.synthetic_dispersions(
+                9000, rocket, motor, wm, H.EXAMPLE_IC, engine.device, precision=_abi.PREC_F64_FAST, seed=5, planar=planar,
+                base_altitude_profile=H.CSV_ALT if csv else None, base_wind_profile=H.CSV_WIND if csv else None, engine=engine)
+            engine.set_adopt(0)
+            engine.set_chunk(0)
+            ref_s, ref_t = (x.clone() for x in engine.run(db, flags=flags))
+            for lanes in (16, 63):
+                engine.set_adopt(lanes)
+                s, t = engine.run(db, flags=flags)
+                engine.last_stats()
+                assert torch.equal(t, ref_t) and same(s, ref_s), (csv, lanes)
+            if csv:
+                assert int(((ref_t & _abi.ST_CHUTE) != 0).sum()) > 100
+    finally:
+        engine.set_adopt(-1)
+        engine.set_chunk(-1)
+
+
+def test_lane_adoption_and_step_chunks_are_exclusive(engine):
+    """With step chunks on, chunk-parked records must not be adopted back inside the launch (measured 8x
+    slower): the library drops the adoption, whatever erpl_mc_set_adopt says - same bits, and the wave
+    iterations of the chunked launch alone."""
+    rocket, motor, wm = models.Rocket(), models.LiquidMotor(), models.WindModel()
+    engine.set_config(H.make_config("liquid"))
+    db = sampling.synthetic_dispersions(20000, rocket, motor, wm, H.EXAMPLE_IC, engine.device, precision=_abi.PREC_F32, seed=9,
+                                        planar=True, engine=engine)
+    try:
+        engine.set_chunk(2048)
+        engine.set_adopt(0)
+        ref_s, ref_t = (x.clone() for x in engine.run(db, flags=_abi.FLAG_STOP_AT_APOGEE))
+        _, wi0 = engine.last_stats()
+        engine.set_adopt(24)
+        s, t = engine.run(db, flags=_abi.FLAG_STOP_AT_APOGEE)
+        _, wi = engine.last_stats()
+        assert torch.equal(t, ref_t) and same(s, ref_s)
+        assert abs(wi - wi0) < 0.01 * wi0     # (which wave pops which record varies from run to run)
+    finally:
+        engine.set_adopt(-1)
+        engine.set_chunk(-1)
+
+
+def test_default_overlap_depth_follows_the_hardware_queues(engine):
+    """The package asks the HIP runtime for 16 hardware queues before its first call (GPU_MAX_HW_QUEUES); with
+    them a fresh context keeps eight batches in flight, and the fp32 default turns lane adoption on there."""
+    import os
+    from erpl_monte_carlo_sim_amd.engine import TrajectoryEngine
+    assert int(os.environ["GPU_MAX_HW_QUEUES"]) >= 10
+    eng = TrajectoryEngine(torch.device("cuda", 0))
+    try:
+        assert eng.get_overlap() == 8
+        eng.set_config(H.make_config("liquid"))
+        rocket, motor, wm = models.Rocket(), models.LiquidMotor(), models.WindModel()
+        db = sampling.synthetic_dispersions(30000, rocket, motor, wm, H.EXAMPLE_IC, eng.device, precision=_abi.PREC_F32, seed=21, engine=eng)
+        ref_s, ref_t = (x.clone() for x in eng.run(db))     # run_batch: one in flight, no adoption
+        _, wi0 = eng.last_stats()
+        s, t = eng.submit(db)
+        eng.wait()
+        _, wi = eng.last_stats()
+        assert torch.equal(t, ref_t) and same(s, ref_s)
+        assert wi < wi0 * 0.97
+        eng.set_overlap(3)                                   # three deep: the batch's own tail bounds it - off
+        s, t = eng.submit(db)
+        eng.wait()
+        _, wi3 = eng.last_stats()
+        assert torch.equal(t, ref_t) and same(s, ref_s) and wi3 == wi0
     finally:
         eng.close()

@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--overlaps", default="0,2,3,4")
     ap.add_argument("--waves", default="2,3")
     ap.add_argument("--max-blocks", default="0", help="workgroup caps to sweep (0 = library default)")
+    ap.add_argument("--adopts", default="0", help="lane-adoption limits to sweep (0 = off)")
     ap.add_argument("--check", action="store_true", help="compare every point's results with the first point's, bit for bit")
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--planar", action="store_true")
@@ -66,9 +67,10 @@ def main():
     rows = []
     ints = lambda s: [int(x) for x in s.split(",")]
     ref = None
-    for block, chunk, waves, ov, mb in itertools.product(ints(a.blocks), ints(a.chunks), ints(a.waves), ints(a.overlaps),
-                                                       ints(a.max_blocks)):
+    for block, chunk, waves, ov, mb, adopt in itertools.product(ints(a.blocks), ints(a.chunks), ints(a.waves), ints(a.overlaps),
+                                                              ints(a.max_blocks), ints(a.adopts)):
         eng.set_launch(block, mb, 1)
+        eng.set_adopt(adopt)
         eng.set_chunk(chunk)
         eng.set_waves_per_simd(waves)
         ms = timed(eng, db, flags, a.reps, ov)
@@ -80,7 +82,7 @@ def main():
                 ref = (s_.clone(), t_.clone())
             same = bool(torch.equal(t_, ref[1]) and ((s_ == ref[0]) | (s_.isnan() & ref[0].isnan())).all())
         steps, wi = eng.last_stats()
-        row = {"bitwise_equal_to_first": same, "util": round(steps / 64 / wi, 3) if wi else None,"lib": os.path.basename(a.lib) if a.lib else "product", "precision": a.precision, "n": a.n, "block": block, "chunk": chunk, "waves": waves, "overlap": ov, "max_blocks": mb,
+        row = {"publish_timeouts": eng.debug_counters()[3], "bitwise_equal_to_first": same, "util": round(steps / 64 / wi, 3) if wi else None,"lib": os.path.basename(a.lib) if a.lib else "product", "precision": a.precision, "n": a.n, "block": block, "chunk": chunk, "waves": waves, "overlap": ov, "max_blocks": mb, "adopt": adopt,
                "ms_per_pass": round(ms, 3), "traj_per_s": round(a.n / ms * 1e3)}
         rows.append(row)
         print(json.dumps(row), flush=True)
