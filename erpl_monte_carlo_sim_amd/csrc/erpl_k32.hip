@@ -10,6 +10,9 @@
 #ifndef ERPL_STAGE_UNROLL
 #define ERPL_STAGE_UNROLL 4
 #endif
+// two resident waves per SIMD for the uncapped build: at most 256 registers (left to itself the allocator took a
+// 257th with the wind prefetch in and halved the occupancy)
+#define ERPL_FLIGHT_MIN_WAVES 2
 #define ERPL_SUFFIX f32
 #define ERPL_CAT_(a, b) a##b
 #define ERPL_CAT(a, b) ERPL_CAT_(a, b)
