@@ -176,7 +176,7 @@ def main():
     rocket, atm, wm = models.Rocket(), models.StandardAtmosphere(), models.WindModel()
     motor = models.SolidMotor() if args.motor == "solid" else models.LiquidMotor()
     cfg = flatten.config_from_objects(rocket, motor, atm)
-    eng = TrajectoryEngine(device)
+    eng = TrajectoryEngine(device, lib_path=os.environ.get("ERPL_LIB"))   # ERPL_LIB: an experiment build of the library (A/B runs)
     eng.set_config(cfg)
     if args.block > 0 or args.max_blocks > 0 or args.refill != 1:
         eng.set_launch(args.block if args.block > 0 else 64, args.max_blocks, args.refill)
@@ -189,11 +189,16 @@ def main():
 
     def leg_depth(precision):
         """Passes in flight for a leg.  All K passes finish inside the timed region, so the pipeline's fill and
-        drain count: at the driver's K = 20 the fp32 kernel is fastest six deep (steady state: eight), the
-        one-wave-per-SIMD fp64 kernels eight deep (measured)."""
+        drain count.  Identical passes submitted together run in step and finish in rounds of `depth`; a last,
+        partial round has the GPU to itself at low occupancy.  The fp32 leg therefore takes the largest depth from
+        4 to the library's that divides K (K = 20: five deep 10.8 ms per pass, six 11.7, eight 11.0; steady state
+        9.45 eight deep); the one-wave-per-SIMD fp64 kernels are fastest eight deep whatever K."""
         if args.overlap >= 0:
             return args.overlap
-        return min(lib_depth, 6) if precision == "f32" else lib_depth
+        if precision == "f32":
+            full_rounds = [d for d in range(4, lib_depth + 1) if args.steps % d == 0]
+            return max(full_rounds) if full_rounds else lib_depth
+        return lib_depth
 
     depth = leg_depth(args.precision)
     n = args.samples_per_gpu

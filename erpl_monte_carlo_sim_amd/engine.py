@@ -21,6 +21,17 @@ class DeviceBatch:
         self.precision = precision
         self.n = int(ic.shape[1])
         self.k_wind = 0 if wind is None else int(wind.shape[0])
+        # the kernels index these by (row, sample) and the knots by row: a wrong shape is an out-of-bounds read on the GPU
+        if wind is not None:
+            if alt_grid is None or tuple(wind.shape) != (self.k_wind, 3, self.n) or alt_grid.numel() != self.k_wind:
+                raise ValueError(f"wind must be (K, 3, n) with K altitudes: got wind {tuple(wind.shape)}, "
+                                 f"altitudes {None if alt_grid is None else tuple(alt_grid.shape)}, n = {self.n}")
+            if not 1 <= self.k_wind <= _abi.MAX_WIND_KNOTS:
+                raise ValueError(f"1..{_abi.MAX_WIND_KNOTS} wind knots, got {self.k_wind}")
+            if alt_grid.dtype != torch.float64 or wind.dtype != (torch.float32 if precision == _abi.PREC_F32 else torch.float64):
+                raise ValueError("altitudes are float64; the wind table is float32 for the fp32 build, float64 otherwise")
+            if not (wind.is_contiguous() and alt_grid.is_contiguous()):
+                raise ValueError("wind and altitudes must be contiguous")
 
     def input_bytes(self):
         b = self.ic.numel() * 8 + self.rocket.numel() * 8 + self.motor.numel() * 8
