@@ -303,3 +303,26 @@ def test_overridden_model_methods_are_refused():
         flatten.config_from_objects(models.Rocket(), patched, models.StandardAtmosphere())
     with pytest.raises(UnsupportedModel, match="SubRocket"):
         flatten.config_from_objects(SubRocket(), models.LiquidMotor(), models.StandardAtmosphere())
+
+
+def test_device_batch_refuses_tables_of_the_wrong_shape():
+    """The kernels index the wind table by (row, sample) and the altitude grid by row; a tensor of another shape
+    would be an out-of-bounds read on the GPU, so the host object refuses it before anything is launched."""
+    import torch
+    from erpl_monte_carlo_sim_amd import _abi
+    from erpl_monte_carlo_sim_amd.engine import DeviceBatch
+    n, k = 8, 5
+    ic, rk, mt = torch.zeros(13, n, dtype=torch.float64), torch.zeros(2, n, dtype=torch.float64), torch.zeros(4, n, dtype=torch.float64)
+    alt = torch.linspace(0, 1000, k, dtype=torch.float64)
+    ok = DeviceBatch(ic, rk, mt, alt, torch.zeros(k, 3, n, dtype=torch.float64), _abi.PREC_F64)
+    assert ok.k_wind == k and ok.n == n
+    assert DeviceBatch(ic, rk, mt, None, None, _abi.PREC_F32).k_wind == 0
+    for bad_alt, bad_wind, prec in (
+            (alt, torch.zeros(k * 3, n, dtype=torch.float64), _abi.PREC_F64),            # flattened rows
+            (alt, torch.zeros(k, 3, n + 1, dtype=torch.float64), _abi.PREC_F64),         # another sample count
+            (alt[:-1], torch.zeros(k, 3, n, dtype=torch.float64), _abi.PREC_F64),        # fewer altitudes than knots
+            (alt, torch.zeros(k, 3, n, dtype=torch.float64), _abi.PREC_F32),             # fp64 table for the fp32 build
+            (alt.float(), torch.zeros(k, 3, n, dtype=torch.float64), _abi.PREC_F64),     # altitudes must be fp64
+            (None, torch.zeros(k, 3, n, dtype=torch.float64), _abi.PREC_F64)):
+        with pytest.raises(ValueError):
+            DeviceBatch(ic, rk, mt, bad_alt, bad_wind, prec)
