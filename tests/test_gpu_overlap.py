@@ -334,7 +334,16 @@ def test_lane_adoption_does_not_change_a_bit(engine, precision):
         engine.synchronize()
         for s, t in outs:
             assert torch.equal(t, ref_t) and same(s, ref_s)
+        # four waves per workgroup, fewer workgroups than the batch has waves (lanes refill from the queue before
+        # the hand-overs start), a refill threshold above one: the geometry must not matter either
+        engine.set_launch(256, max(1, n // 256 // 3), 4)
+        outs = [engine.submit(db) for _ in range(8)]
+        engine.wait()
+        engine.synchronize()
+        for s, t in outs:
+            assert torch.equal(t, ref_t) and same(s, ref_s)
     finally:
+        engine.set_launch(64, 0, 1)
         engine.set_adopt(-1)
         engine.set_chunk(-1)
         engine.set_overlap(3)
