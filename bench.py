@@ -39,7 +39,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # one hardware queue per batch in flight (include/erpl_mc.h), before HIP starts
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")   # one hardware queue per batch in flight (include/erpl_mc.h), before HIP starts
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -5,7 +5,7 @@ import os as _os
 
 # Eight batches in flight need a hardware queue each (include/erpl_mc.h, erpl_mc_set_overlap); the HIP
 # runtime reads the limit once, at its first call - which a bare `import torch` has not made yet.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 from .models import Rocket, SolidMotor, LiquidMotor, StandardAtmosphere, WindModel  # noqa: F401
 

@@ -225,8 +225,8 @@ struct ErplSlot {
   unsigned long long* d_queue = nullptr;    // qcnt[ERPL_MAX_PHASES + 2] followed by qhead[...]
   unsigned long long* d_counters = nullptr; // 16 words
   int64_t cap = 0;
-  hipStream_t stream = nullptr;             // internal stream (created on first submit)
-  hipEvent_t in_ready = nullptr, done = nullptr;
+  hipEvent_t done = nullptr;                // everything of the slot's latest batch has run
+  hipEvent_t main_done = nullptr;           // its main flight launch has (the sweep stream waits for this)
   bool used = false;                        // `done` has been recorded at least once
   int64_t ticket = 0;                       // last batch submitted through this slot
   unsigned long long* h_counters = nullptr; // pinned host copy of d_counters[0..3] of the slot's latest batch
@@ -239,7 +239,17 @@ struct erpl_ctx {
   bool has_cfg = false;
   ErplTables h_tables;            // host copy (scalars are passed to the kernels by value)
   ErplTables* d_tables = nullptr;
-  ErplSlot slot[ERPL_MAX_OVERLAP];
+  // Two workspaces ("sets") per lane of erpl_mc_submit_batch, used alternately: slot[lane] and
+  // slot[ERPL_MAX_OVERLAP + lane].  A batch with lane adoption runs its rail and main flight launch on the lane's
+  // main stream and its sweep launches (the few long trajectories nobody adopted) on the lane's sweep stream, so
+  // the lane's NEXT batch - on the other set - starts when the main launch is over and overlaps the sweeps:
+  // batches of equal length submitted together run in step, and without this the tails of a whole round of
+  // them met on an otherwise empty GPU before the next round could start.
+  ErplSlot slot[2 * ERPL_MAX_OVERLAP];
+  hipStream_t lane_stream[ERPL_MAX_OVERLAP] = {};
+  hipStream_t lane_sweep[ERPL_MAX_OVERLAP] = {};
+  hipEvent_t lane_in_ready[ERPL_MAX_OVERLAP] = {};
+  unsigned lane_uses[ERPL_MAX_OVERLAP] = {};   // batches the lane has taken: parity picks the set
   int depth = 3;                  // slots erpl_mc_submit_batch cycles through (erpl_mc_create: 8 with enough hardware queues)
   int64_t submitted = 0;          // tickets handed out
   int last_slot = 0;              // slot of the most recent batch (erpl_mc_last_stats)
@@ -286,8 +296,8 @@ int slot_init(ErplSlot& s) {
   if (s.d_queue) return ERPL_OK;
   HIP_TRY(hipMalloc((void**)&s.d_counters, 16 * sizeof(unsigned long long)));
   HIP_TRY(hipMalloc((void**)&s.d_queue, 2 * (ERPL_MAX_PHASES + 2) * sizeof(unsigned long long)));
-  HIP_TRY(hipEventCreateWithFlags(&s.in_ready, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&s.main_done, hipEventDisableTiming));
   HIP_TRY(hipHostMalloc((void**)&s.h_counters, 4 * sizeof(unsigned long long), hipHostMallocDefault));
   memset(s.h_counters, 0, 4 * sizeof(unsigned long long));
   return ERPL_OK;
@@ -296,9 +306,8 @@ int slot_init(ErplSlot& s) {
 void slot_destroy(ErplSlot& s) {
   slot_free_workspace(s);
   (void)hipFree(s.d_counters); (void)hipFree(s.d_queue);
-  if (s.in_ready) (void)hipEventDestroy(s.in_ready);
   if (s.done) (void)hipEventDestroy(s.done);
-  if (s.stream) (void)hipStreamDestroy(s.stream);
+  if (s.main_done) (void)hipEventDestroy(s.main_done);
   if (s.h_counters) (void)hipHostFree(s.h_counters);
   s = ErplSlot();
 }
@@ -332,8 +341,11 @@ void fill_common_args(const erpl_ctx* c, const erpl_batch* b, ErplKArgs& a) {
   a.dt_rail = T.dt_rail; a.dt_flight = T.dt_flight; a.max_time = T.max_time;
 }
 
-// Rail + flight kernels of one batch through slot `si`, on stream `st`.
-int enqueue_batch(erpl_ctx* c, int si, const erpl_batch* b, const erpl_out* o, hipStream_t st, int in_flight) {
+// Rail + flight kernels of one batch through the lane's next set, on stream `st`; `sweep` (or NULL) = the stream
+// the launches behind the main one go to when the batch runs with lane adoption.
+int enqueue_batch(erpl_ctx* c, int lane, const erpl_batch* b, const erpl_out* o, hipStream_t st, int in_flight,
+                  hipStream_t sweep, int64_t ticket) {
+  const int si = lane + (int)(c->lane_uses[lane] & 1u) * ERPL_MAX_OVERLAP;
   ErplSlot& s = c->slot[si];
   int rc = slot_init(s);
   if (rc != ERPL_OK) return rc;
@@ -372,7 +384,7 @@ int enqueue_batch(erpl_ctx* c, int si, const erpl_batch* b, const erpl_out* o, h
   // Results do not depend on the choice (bitwise).
   int chunk_steps = c->chunk;
   if (chunk_steps < 0) {
-    for (int i = 0; i < ERPL_MAX_OVERLAP; ++i) {
+    for (int i = 0; i < 2 * ERPL_MAX_OVERLAP; ++i) {
       ErplSlot& q = c->slot[i];
       if (q.used && q.seq > c->seen_seq && q.last_n > 0 && hipEventQuery(q.done) == hipSuccess) {
         c->seen_mean_steps = (double)q.h_counters[1] / (double)q.last_n;
@@ -388,36 +400,44 @@ int enqueue_batch(erpl_ctx* c, int si, const erpl_batch* b, const erpl_out* o, h
     a.chunk_steps = (int)chunk;
     n_phases = (int)ceil(max_steps / chunk) + 1;
   }
-  // lane adoption (erpl_mc_set_adopt): two sweep launches behind the main one fly out what no running wave
-  // adopted - the first parks its own thin waves once more, the last one never parks
-  // Automatic (erpl_mc_set_adopt < 0, the default): fp32 batches with at least five in flight on queues of their
-  // own.  There the GPU is short of issue slots, not of batches, and the 15-20 % fewer wave-iterations pay
-  // (131 072 samples, eight deep: 11.6 -> 10.3 ms); with three in flight the batch's own longest trajectory
-  // bounds it and the hand-overs only lengthen that (12.2 -> 15.1 ms).  The fp64 builds run one wave per SIMD
-  // and gain nothing (measured); step chunks already re-pack every lane, and chunk-parked records would be
-  // adopted straight back (measured 8x slower), so the two are exclusive.
+  // Lane adoption (erpl_mc_set_adopt): two sweep launches behind the main one fly out what no running wave
+  // adopted - the first parks its own thin waves once more, the last one never parks.
+  // Automatic (erpl_mc_set_adopt < 0, the default): every batch handed over with erpl_mc_submit_batch while at least
+  // two may be in flight and the lanes have hardware queues of their own (two streams each).  The sweeps run on
+  // the lane's second stream, so the next batch of the lane follows the main launch at once and the few long
+  // trajectories of a batch finish beside it (131 072 samples, fp32: 16.6 -> 10.7 ms two deep, 11.6 -> 8.9 three
+  // deep, 10.9 -> 8.9 eight deep; fp64 throughput build 44.7 -> 38.1 three deep, 37.7 -> 35.9 eight deep; the
+  // gate kernel 129 -> 116 three deep).  A batch alone (erpl_mc_run_batch, or depth 1) is bound by its own
+  // longest trajectory, which the hand-overs only lengthen (32.8 -> 36.8 ms): off.  Step chunks already re-pack
+  // every lane, and chunk-parked records would be adopted straight back (measured 8x slower): exclusive.
   int adopt = c->adopt;
-  if (adopt < 0) adopt = (b->precision == ERPL_PREC_F32 && in_flight >= 5 && hw_queues_env() >= in_flight + 2) ? 24 : 0;
+  if (adopt < 0) adopt = (sweep && in_flight >= 2 && hw_queues_env() >= 2 * in_flight + 2) ? 24 : 0;
   a.adopt_lanes = (o->n_traj == 0 && a.chunk_steps == 0) ? adopt : 0;
   if (a.adopt_lanes > 0 && n_phases < 3) n_phases = 3;
   void** ev = c->profiling ? (void**)&c->ev[3 * (c->profiled_runs % ERPL_PROFILE_RING)] : nullptr;
+  // with lane adoption the launches behind the main one hold the batch's few longest trajectories: they go to the
+  // lane's sweep stream, and the lane's next batch (other set) follows the main launch at once
+  hipStream_t tail = (sweep && a.adopt_lanes > 0) ? sweep : nullptr;
   int lrc;
-  if (b->precision == ERPL_PREC_F64) lrc = erpl_launch_f64(a, &T.s64, c->block, max_blocks, n_phases, st, ev);
-  else if (b->precision == ERPL_PREC_F64_FAST) lrc = erpl_launch_f64f(a, &T.s64, c->block, max_blocks, n_phases, st, ev);
-  else lrc = erpl_launch_f32(a, &T.s32, c->block, max_blocks, n_phases, st, ev);
+  if (b->precision == ERPL_PREC_F64) lrc = erpl_launch_f64(a, &T.s64, c->block, max_blocks, n_phases, st, ev, tail, s.main_done);
+  else if (b->precision == ERPL_PREC_F64_FAST) lrc = erpl_launch_f64f(a, &T.s64, c->block, max_blocks, n_phases, st, ev, tail, s.main_done);
+  else lrc = erpl_launch_f32(a, &T.s32, c->block, max_blocks, n_phases, st, ev, tail, s.main_done);
   if (c->profiling && lrc == 0) c->profiled_runs++;
   if (lrc != 0) return fail(ERPL_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
-  HIP_TRY(hipMemcpyAsync(s.h_counters, s.d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipEventRecord(s.done, st));
+  hipStream_t last = tail ? tail : st;
+  HIP_TRY(hipMemcpyAsync(s.h_counters, s.d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, last));
+  HIP_TRY(hipEventRecord(s.done, last));
   s.used = true;
+  if (ticket > 0) s.ticket = ticket;   // (an erpl_mc_run_batch on this set leaves the ticket: its `done` is later and covers it)
   s.last_n = b->n;
   s.seq = ++c->batches;
   c->last_slot = si;
+  c->lane_uses[lane]++;
   return ERPL_OK;
 }
 
 int wait_all_host(erpl_ctx* c) {
-  for (int i = 0; i < ERPL_MAX_OVERLAP; ++i)
+  for (int i = 0; i < 2 * ERPL_MAX_OVERLAP; ++i)
     if (c->slot[i].used) HIP_TRY(hipEventSynchronize(c->slot[i].done));
   return ERPL_OK;
 }
@@ -440,7 +460,8 @@ int erpl_mc_create(int device, erpl_ctx** out) {
   c->device = device;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
-  c->depth = (hw_queues_env() >= ERPL_MAX_OVERLAP + 2) ? ERPL_MAX_OVERLAP : 3;   // + the caller's stream and one more of its own
+  // two streams per lane (main, sweep) + the caller's stream and one more of its own
+  c->depth = (hw_queues_env() >= 2 * ERPL_MAX_OVERLAP + 2) ? ERPL_MAX_OVERLAP : ((hw_queues_env() >= 12) ? (hw_queues_env() - 2) / 2 : 3);
   hipError_t e = hipMalloc((void**)&c->d_tables, sizeof(ErplTables));
   for (int i = 0; i < 3 * ERPL_PROFILE_RING && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
   if (e != hipSuccess) { (void)erpl_mc_destroy(c); return fail(ERPL_ERR_HIP, "hipMalloc/hipEventCreate: %s", hipGetErrorString(e)); }
@@ -454,7 +475,12 @@ int erpl_mc_destroy(erpl_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)wait_all_host(c);
   (void)hipFree(c->d_tables);
-  for (int i = 0; i < ERPL_MAX_OVERLAP; ++i) slot_destroy(c->slot[i]);
+  for (int i = 0; i < 2 * ERPL_MAX_OVERLAP; ++i) slot_destroy(c->slot[i]);
+  for (int i = 0; i < ERPL_MAX_OVERLAP; ++i) {
+    if (c->lane_stream[i]) (void)hipStreamDestroy(c->lane_stream[i]);
+    if (c->lane_sweep[i]) (void)hipStreamDestroy(c->lane_sweep[i]);
+    if (c->lane_in_ready[i]) (void)hipEventDestroy(c->lane_in_ready[i]);
+  }
   for (int i = 0; i < 3 * ERPL_PROFILE_RING; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   delete c;
   return ERPL_OK;
@@ -479,8 +505,8 @@ int erpl_mc_reserve(erpl_ctx* c, int64_t n) {
   if (n > c->reserve_n) c->reserve_n = n;
   // slot 0 now (erpl_mc_run_batch stays allocation-free, hence graph-capturable); the overlap slots
   // that have been used before grow too, fresh ones take the size on first use
-  for (int i = 0; i < ERPL_MAX_OVERLAP; ++i) {
-    if (i > 0 && !c->slot[i].d_queue) continue;
+  for (int i = 0; i < 2 * ERPL_MAX_OVERLAP; ++i) {
+    if (i % ERPL_MAX_OVERLAP != 0 && !c->slot[i].d_queue) continue;   // both sets of lane 0: erpl_mc_run_batch alternates too
     int rc = slot_init(c->slot[i]);
     if (rc == ERPL_OK) rc = slot_reserve(c->slot[i], c->reserve_n);
     if (rc != ERPL_OK) return rc;
@@ -523,7 +549,7 @@ int erpl_mc_run_batch(erpl_ctx* c, const erpl_batch* b, const erpl_out* o, void*
   int rc = check_batch(c, b, o);
   if (rc != ERPL_OK || b->n == 0) return rc;
   HIP_TRY(hipSetDevice(c->device));
-  return enqueue_batch(c, 0, b, o, (hipStream_t)stream, 1);
+  return enqueue_batch(c, 0, b, o, (hipStream_t)stream, 1, nullptr, 0);
 }
 
 int erpl_mc_get_overlap(erpl_ctx* c) { return c ? c->depth : 0; }
@@ -544,18 +570,20 @@ int erpl_mc_submit_batch(erpl_ctx* c, const erpl_batch* b, const erpl_out* o, vo
   if (ticket) *ticket = c->submitted;   // an empty batch is complete as soon as its predecessors are
   if (b->n == 0) return ERPL_OK;
   HIP_TRY(hipSetDevice(c->device));
-  const int si = (int)(c->submitted % c->depth);
-  ErplSlot& s = c->slot[si];
-  rc = slot_init(s);
-  if (rc != ERPL_OK) return rc;
-  if (!s.stream) HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+  const int lane = (int)(c->submitted % c->depth);
+  if (!c->lane_stream[lane]) HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream[lane], hipStreamNonBlocking));
+  // the sweep stream only where lane adoption can come on: a stream takes a hardware queue, and with the HIP default
+  // of four a second one per lane would push the main streams onto shared queues
+  const bool may_adopt = c->adopt > 0 || (c->adopt < 0 && c->depth >= 2 && hw_queues_env() >= 2 * c->depth + 2);
+  if (may_adopt && !c->lane_sweep[lane]) HIP_TRY(hipStreamCreateWithFlags(&c->lane_sweep[lane], hipStreamNonBlocking));
+  if (!c->lane_in_ready[lane]) HIP_TRY(hipEventCreateWithFlags(&c->lane_in_ready[lane], hipEventDisableTiming));
   // inputs written on the caller's stream so far are visible to the batch
-  HIP_TRY(hipEventRecord(s.in_ready, (hipStream_t)stream));
-  HIP_TRY(hipStreamWaitEvent(s.stream, s.in_ready, 0));
-  rc = enqueue_batch(c, si, b, o, s.stream, c->depth);
+  HIP_TRY(hipEventRecord(c->lane_in_ready[lane], (hipStream_t)stream));
+  HIP_TRY(hipStreamWaitEvent(c->lane_stream[lane], c->lane_in_ready[lane], 0));
+  rc = enqueue_batch(c, lane, b, o, c->lane_stream[lane], c->depth, may_adopt ? c->lane_sweep[lane] : nullptr, c->submitted + 1);
   if (rc != ERPL_OK) return rc;
-  s.ticket = ++c->submitted;
-  if (ticket) *ticket = s.ticket;
+  ++c->submitted;
+  if (ticket) *ticket = c->submitted;
   return ERPL_OK;
 }
 
@@ -563,11 +591,20 @@ int erpl_mc_wait_batch(erpl_ctx* c, int64_t ticket, void* stream) {
   if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
   if (ticket > c->submitted) return fail(ERPL_ERR_INVALID, "ticket %lld has not been handed out", (long long)ticket);
   HIP_TRY(hipSetDevice(c->device));
-  for (int i = 0; i < ERPL_MAX_OVERLAP; ++i) {
+  // The set that ran the batch still carries its ticket unless the lane has reused it since - and a set is reused
+  // only behind its previous batch (enqueue_batch waits for `done`), so then the later ticket's event covers it.
+  // (erpl_mc_run_batch's batches carry ticket 0 and are ordered by the caller's own stream.)
+  bool exact = false;
+  for (int i = 0; i < 2 * ERPL_MAX_OVERLAP && ticket > 0; ++i)
+    if (c->slot[i].used && c->slot[i].ticket == ticket) {
+      HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, c->slot[i].done, 0));
+      exact = true;
+    }
+  if (exact) return ERPL_OK;
+  for (int i = 0; i < 2 * ERPL_MAX_OVERLAP; ++i) {
     ErplSlot& s = c->slot[i];
-    if (!s.used || !s.stream) continue;
-    // a slot's stream runs its batches in order: the event of a later ticket covers the earlier ones
-    if (ticket < 0 || (s.ticket >= ticket && (s.ticket - ticket) % c->depth == 0))
+    if (!s.used || s.ticket <= 0) continue;
+    if (ticket < 0 || (s.ticket > ticket && (s.ticket - ticket) % c->depth == 0))
       HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, s.done, 0));
   }
   return ERPL_OK;
@@ -578,7 +615,7 @@ int erpl_mc_synchronize(erpl_ctx* c) {
   HIP_TRY(hipSetDevice(c->device));
   const int rc = wait_all_host(c);
   if (rc != ERPL_OK) return rc;
-  for (int i = 0; i < ERPL_MAX_OVERLAP; ++i)   // counters of every finished batch sit in pinned memory
+  for (int i = 0; i < 2 * ERPL_MAX_OVERLAP; ++i)   // counters of every finished batch sit in pinned memory
     if (c->slot[i].used && c->slot[i].h_counters[3] != 0ull)
       return fail(ERPL_ERR_HIP, "lane hand-over timed out in batch %lld: its results are incomplete", (long long)c->slot[i].ticket);
   return ERPL_OK;

@@ -122,9 +122,14 @@ extern "C++" {
 // (kernel-argument segment -> scalar registers; a pointer into global memory would be re-read
 // through the vector memory path on every use because the kernels also store to global memory).
 // n_phases flight launches follow the rail launch (1 when a.chunk_steps <= 0).
-int erpl_launch_f64(const ErplKArgs& a, const void* scalars, int block, int max_blocks, int n_phases, void* stream, void** ev);
-int erpl_launch_f32(const ErplKArgs& a, const void* scalars, int block, int max_blocks, int n_phases, void* stream, void** ev);
-int erpl_launch_f64f(const ErplKArgs& a, const void* scalars, int block, int max_blocks, int n_phases, void* stream, void** ev);
+// tail_stream (or NULL): the launches behind the first go to that stream, after main_done (a hipEvent_t recorded on
+// `stream` behind the first launch).
+int erpl_launch_f64(const ErplKArgs& a, const void* scalars, int block, int max_blocks, int n_phases, void* stream, void** ev,
+                    void* tail_stream, void* main_done);
+int erpl_launch_f32(const ErplKArgs& a, const void* scalars, int block, int max_blocks, int n_phases, void* stream, void** ev,
+                    void* tail_stream, void* main_done);
+int erpl_launch_f64f(const ErplKArgs& a, const void* scalars, int block, int max_blocks, int n_phases, void* stream, void** ev,
+                    void* tail_stream, void* main_done);
 // known-answer evaluation of one device function per lane (erpl_mc_debug_eval); in / out are [rows][m]
 int erpl_launch_debug_f64(const ErplKArgs& a, const void* scalars, int what, int64_t m, const double* in, double* out, void* stream);
 int erpl_launch_debug_f32(const ErplKArgs& a, const void* scalars, int what, int64_t m, const double* in, double* out, void* stream);

@@ -196,12 +196,13 @@ int erpl_mc_run_batch(erpl_ctx* ctx, const erpl_batch* batch, const erpl_out* ou
  * submitted so far); the host never blocks.  Output buffers belong to the batch until then.  Results
  * are bitwise those of erpl_mc_run_batch.  depth 1..8; changing it waits for work in flight.
  *
- * Each internal stream needs a hardware queue of its own to overlap with the others.  The HIP runtime
- * gives a process GPU_MAX_HW_QUEUES of them (environment variable, read when the runtime initialises,
- * default 4) and puts further streams on the same queues, where their kernels run one after the other:
- * with the default, four or five batches in flight are slower than three.  The default depth is therefore
- * 3, or 8 if GPU_MAX_HW_QUEUES >= 10 is in the environment at erpl_mc_create (the host sets it before its
- * first HIP call; the Python package does so on import).  erpl_mc_get_overlap returns the depth in use. */
+ * Each internal stream needs a hardware queue of its own to overlap with the others, and every lane has two
+ * (main launches, sweep launches - erpl_mc_set_adopt).  The HIP runtime gives a process GPU_MAX_HW_QUEUES of
+ * them (environment variable, read when the runtime initialises, default 4) and puts further streams on the
+ * same queues, where their kernels run one after the other: with the default, four or five batches in flight
+ * are slower than three.  The default depth is therefore 3, or (GPU_MAX_HW_QUEUES - 2) / 2 up to 8 if
+ * GPU_MAX_HW_QUEUES >= 12 is in the environment at erpl_mc_create (the host sets it before its first HIP call;
+ * the Python package sets 24 on import).  erpl_mc_get_overlap returns the depth in use. */
 #define ERPL_MAX_OVERLAP 8
 int erpl_mc_set_overlap(erpl_ctx* ctx, int depth);
 int erpl_mc_get_overlap(erpl_ctx* ctx);
@@ -231,11 +232,13 @@ int erpl_mc_set_chunk(erpl_ctx* ctx, int chunk_steps);
 /* Lane adoption (no reference counterpart; scheduling only).  Once the sample queue is empty, a wave of the
  * flight kernel left with at most `lanes` flying trajectories writes them to the resume queue and leaves;
  * waves of the same launch that still fly more adopt them into their idle lanes, and two short sweep
- * launches fly out what nobody adopted.  0 = off; < 0 (the default) = 24 for fp32 batches submitted with
- * at least five in flight on hardware queues of their own (see erpl_mc_set_overlap), where fewer
- * wave-iterations mean less time (-10 %); off otherwise (with three in flight a batch is bound by its
- * longest trajectory, which the hand-overs lengthen) and whenever step chunks are in use.  Results do not
- * depend on the value (bitwise). */
+ * launches fly out what nobody adopted.  For batches handed over with erpl_mc_submit_batch the sweeps run on
+ * a second internal stream of the lane and the lane's next batch (on a second workspace) follows the main
+ * launch at once, so the few long trajectories of a batch finish beside the next one.  0 = off; < 0 (the
+ * default) = 24 for every batch submitted while two or more may be in flight on hardware queues of their own
+ * (2 x depth + 2, see erpl_mc_set_overlap), off for erpl_mc_run_batch (a batch alone is bound by its longest
+ * trajectory, which the hand-overs lengthen) and whenever step chunks are in use.  Results do not depend on
+ * the value (bitwise). */
 int erpl_mc_set_adopt(erpl_ctx* ctx, int lanes);
 
 /* Diagnostics of the last run_batch on this ctx (after the stream has been synchronised):

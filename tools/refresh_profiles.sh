@@ -5,7 +5,7 @@
 tag="$1"
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 # rocprofv3 starts the HIP runtime before python does: the hardware-queue limit the package sets on import must already be there
-export GPU_MAX_HW_QUEUES=16
+export GPU_MAX_HW_QUEUES=24
 B="python3 bench.py --steps 6 --warmup 3 --cpu-seconds 0 --no-parity"
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err &&
 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_stats -o run --output-format csv -- $B > gpurun_out/${tag}_stats.log 2>&1 &&
