@@ -402,16 +402,18 @@ int enqueue_batch(erpl_ctx* c, int lane, const erpl_batch* b, const erpl_out* o,
   }
   // Lane adoption (erpl_mc_set_adopt): two sweep launches behind the main one fly out what no running wave
   // adopted - the first parks its own thin waves once more, the last one never parks.
-  // Automatic (erpl_mc_set_adopt < 0, the default): every batch handed over with erpl_mc_submit_batch while at least
-  // two may be in flight and the lanes have hardware queues of their own (two streams each).  The sweeps run on
-  // the lane's second stream, so the next batch of the lane follows the main launch at once and the few long
-  // trajectories of a batch finish beside it (131 072 samples, fp32: 16.6 -> 10.7 ms two deep, 11.6 -> 8.9 three
-  // deep, 10.9 -> 8.9 eight deep; fp64 throughput build 44.7 -> 38.1 three deep, 37.7 -> 35.9 eight deep; the
-  // gate kernel 129 -> 116 three deep).  A batch alone (erpl_mc_run_batch, or depth 1) is bound by its own
-  // longest trajectory, which the hand-overs only lengthen (32.8 -> 36.8 ms): off.  Step chunks already re-pack
-  // every lane, and chunk-parked records would be adopted straight back (measured 8x slower): exclusive.
+  // Automatic (erpl_mc_set_adopt < 0, the default): every batch handed over with erpl_mc_submit_batch while the lanes
+  // have hardware queues of their own (two streams each: 2 x depth + 2 with the caller's).  The sweeps run on the
+  // lane's second stream, so the next batch of the lane follows the main launch at once and the few long
+  // trajectories of a batch finish beside it (131 072 samples, fp32: 32.4 -> 20.8 ms one deep, 16.5 -> 10.8 two
+  // deep, 11.3 -> 9.0 three deep, 10.6 -> 9.0 eight deep; fp64 throughput build 44.7 -> 38.1 three deep, 37.7 ->
+  // 35.9 eight deep; the gate kernel 129 -> 116 three deep).  Without the queues the second stream of a lane
+  // lands on another lane's queue and the hand-overs cost more than they save (four queues, three deep: 11.4 ->
+  // 25.5 ms): off.  erpl_mc_run_batch runs on the caller's one stream, where a batch is bound by its own longest
+  // trajectory and the hand-overs only lengthen that (32.5 -> 36.1 ms): off.  Step chunks already re-pack every
+  // lane, and chunk-parked records would be adopted straight back (measured 8x slower): exclusive.
   int adopt = c->adopt;
-  if (adopt < 0) adopt = (sweep && in_flight >= 2 && hw_queues_env() >= 2 * in_flight + 2) ? 24 : 0;
+  if (adopt < 0) adopt = (sweep && hw_queues_env() >= 2 * in_flight + 2) ? 24 : 0;
   a.adopt_lanes = (o->n_traj == 0 && a.chunk_steps == 0) ? adopt : 0;
   if (a.adopt_lanes > 0 && n_phases < 3) n_phases = 3;
   void** ev = c->profiling ? (void**)&c->ev[3 * (c->profiled_runs % ERPL_PROFILE_RING)] : nullptr;
@@ -574,7 +576,7 @@ int erpl_mc_submit_batch(erpl_ctx* c, const erpl_batch* b, const erpl_out* o, vo
   if (!c->lane_stream[lane]) HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream[lane], hipStreamNonBlocking));
   // the sweep stream only where lane adoption can come on: a stream takes a hardware queue, and with the HIP default
   // of four a second one per lane would push the main streams onto shared queues
-  const bool may_adopt = c->adopt > 0 || (c->adopt < 0 && c->depth >= 2 && hw_queues_env() >= 2 * c->depth + 2);
+  const bool may_adopt = c->adopt > 0 || (c->adopt < 0 && hw_queues_env() >= 2 * c->depth + 2);
   if (may_adopt && !c->lane_sweep[lane]) HIP_TRY(hipStreamCreateWithFlags(&c->lane_sweep[lane], hipStreamNonBlocking));
   if (!c->lane_in_ready[lane]) HIP_TRY(hipEventCreateWithFlags(&c->lane_in_ready[lane], hipEventDisableTiming));
   // inputs written on the caller's stream so far are visible to the batch

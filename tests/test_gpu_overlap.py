@@ -402,7 +402,7 @@ def test_lane_adoption_and_step_chunks_are_exclusive(engine):
 def test_default_overlap_depth_follows_the_hardware_queues(engine):
     """The package asks the HIP runtime for 24 hardware queues before its first call (GPU_MAX_HW_QUEUES); with
     them a fresh context keeps eight batches in flight (two streams each), and the default turns lane adoption on
-    for submitted batches from two in flight up - not for a batch that runs alone."""
+    for submitted batches - not for erpl_mc_run_batch on the caller's stream."""
     import os
     from erpl_monte_carlo_sim_amd.engine import TrajectoryEngine
     assert int(os.environ["GPU_MAX_HW_QUEUES"]) >= 18
@@ -424,10 +424,12 @@ def test_default_overlap_depth_follows_the_hardware_queues(engine):
         eng.wait()
         _, wi3 = eng.last_stats()
         assert torch.equal(t, ref_t) and same(s, ref_s) and wi3 < wi0 * 0.97
-        eng.set_overlap(1)                                   # one at a time: the batch's own tail bounds it - off
-        s, t = eng.submit(db)
+        eng.set_overlap(1)                                   # one lane: its two sets and streams still pipeline
+        outs = [eng.submit(db) for _ in range(3)]
         eng.wait()
         _, wi1 = eng.last_stats()
-        assert torch.equal(t, ref_t) and same(s, ref_s) and wi1 == wi0
+        assert wi1 < wi0 * 0.97
+        for s, t in outs:
+            assert torch.equal(t, ref_t) and same(s, ref_s)
     finally:
         eng.close()
