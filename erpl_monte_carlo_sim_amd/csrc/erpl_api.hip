@@ -505,10 +505,11 @@ int erpl_mc_reserve(erpl_ctx* c, int64_t n) {
   if (!c || n < 0) return fail(ERPL_ERR_INVALID, "bad argument");
   HIP_TRY(hipSetDevice(c->device));
   if (n > c->reserve_n) c->reserve_n = n;
-  // slot 0 now (erpl_mc_run_batch stays allocation-free, hence graph-capturable); the overlap slots
+  // both workspaces of every lane in use now (erpl_mc_run_batch on lane 0 stays allocation-free, hence
+  // graph-capturable, and no erpl_mc_submit_batch allocates in the middle of a run); lanes beyond the current depth
   // that have been used before grow too, fresh ones take the size on first use
   for (int i = 0; i < 2 * ERPL_MAX_OVERLAP; ++i) {
-    if (i % ERPL_MAX_OVERLAP != 0 && !c->slot[i].d_queue) continue;   // both sets of lane 0: erpl_mc_run_batch alternates too
+    if (i % ERPL_MAX_OVERLAP >= c->depth && !c->slot[i].d_queue) continue;
     int rc = slot_init(c->slot[i]);
     if (rc == ERPL_OK) rc = slot_reserve(c->slot[i], c->reserve_n);
     if (rc != ERPL_OK) return rc;

@@ -176,8 +176,9 @@ int erpl_mc_destroy(erpl_ctx* ctx);
 /* Copies and validates cfg, derives the interval tables and uploads them. */
 int erpl_mc_set_config(erpl_ctx* ctx, const erpl_config* cfg);
 
-/* Grows the context workspace for batches of up to n samples (hipMalloc happens here, never in
- * run_batch once the workspace is large enough, so run_batch is graph-capturable). */
+/* Grows the context workspace for batches of up to n samples: both workspaces of every lane within the current
+ * overlap depth (hipMalloc happens here, never in run_batch / submit_batch once the workspace is large enough, so
+ * run_batch is graph-capturable and a run of submits does not allocate half way). */
 int erpl_mc_reserve(erpl_ctx* ctx, int64_t n);
 
 /* Enqueues rail phase + flight integration + summaries for the batch on `hip_stream`
