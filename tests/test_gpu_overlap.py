@@ -433,3 +433,35 @@ def test_default_overlap_depth_follows_the_hardware_queues(engine):
             assert torch.equal(t, ref_t) and same(s, ref_s)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("depth", [1, 2, 5])
+def test_tickets_are_waitable_one_by_one_in_any_order(engine, depth):
+    """Every lane alternates between two workspaces and runs a batch's sweep launches on a second stream, so two
+    batches of a lane can be in flight and a later one can finish first.  erpl_mc_wait_batch(ticket) must order the
+    stream behind exactly that batch however old the ticket is: 13 different batches, each with its own output
+    buffers, waited for newest first / oldest first / shuffled on a side stream that copies the results out with no
+    host synchronisation in between."""
+    engine.set_config(H.make_config("liquid"))
+    dbs = batches(engine, _abi.PREC_F32, 13, n=5000)
+    serial = [tuple(x.clone() for x in engine.run(db)) for db in dbs]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(engine.device)
+    engine.set_overlap(depth)
+    try:
+        for order in (list(range(12, -1, -1)), list(range(13)), [7, 0, 12, 3, 9, 1, 11, 5, 2, 10, 4, 8, 6]):
+            outs, tickets = [], []
+            for db in dbs:
+                outs.append(engine.submit(db))
+                tickets.append(engine.last_ticket)
+            copies = {}
+            with torch.cuda.stream(side):
+                for i in order:
+                    engine.wait(tickets[i], side)
+                    copies[i] = (outs[i][0].clone(), outs[i][1].clone())
+            side.synchronize()
+            for i in range(13):
+                assert torch.equal(copies[i][1], serial[i][1]) and same(copies[i][0], serial[i][0]), (depth, i)
+            engine.synchronize()
+    finally:
+        engine.set_overlap(3)
