@@ -413,7 +413,9 @@ int enqueue_batch(erpl_ctx* c, int lane, const erpl_batch* b, const erpl_out* o,
   // trajectory and the hand-overs only lengthen that (32.5 -> 36.1 ms): off.  Step chunks already re-pack every
   // lane, and chunk-parked records would be adopted straight back (measured 8x slower): exclusive.
   int adopt = c->adopt;
-  if (adopt < 0) adopt = (sweep && hw_queues_env() >= 2 * in_flight + 2) ? 24 : 0;
+  // (limit: fp32 12 / 16 / 24 / 32 / 48 -> 9.30 / 9.05 / 9.00 / 8.93 / 8.97 ms; the one-wave-per-SIMD fp64 builds like it
+  // higher - 24 / 40 / 48 / 56 -> 35.7 / 34.8 / 35.3 / 35.3 ms eight deep, 40.3 / 38.4 / 38.2 / 40.9 three deep)
+  if (adopt < 0) adopt = (sweep && hw_queues_env() >= 2 * in_flight + 2) ? (b->precision == ERPL_PREC_F32 ? 24 : 40) : 0;
   a.adopt_lanes = (o->n_traj == 0 && a.chunk_steps == 0) ? adopt : 0;
   if (a.adopt_lanes > 0 && n_phases < 3) n_phases = 3;
   void** ev = c->profiling ? (void**)&c->ev[3 * (c->profiled_runs % ERPL_PROFILE_RING)] : nullptr;

@@ -236,7 +236,7 @@ int erpl_mc_set_chunk(erpl_ctx* ctx, int chunk_steps);
  * launches fly out what nobody adopted.  For batches handed over with erpl_mc_submit_batch the sweeps run on
  * a second internal stream of the lane and the lane's next batch (on a second workspace) follows the main
  * launch at once, so the few long trajectories of a batch finish beside the next one.  0 = off; < 0 (the
- * default) = 24 for every batch handed over with erpl_mc_submit_batch when the lanes have hardware queues of
+ * default) = 24 (fp32) / 40 (fp64 builds) for every batch handed over with erpl_mc_submit_batch when the lanes have hardware queues of
  * their own (GPU_MAX_HW_QUEUES >= 2 x depth + 2, see erpl_mc_set_overlap), off without them, for
  * erpl_mc_run_batch (on the caller's one stream a batch is bound by its longest trajectory, which the
  * hand-overs lengthen) and whenever step chunks are in use.  Results do not depend on the value (bitwise). */
