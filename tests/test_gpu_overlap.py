@@ -465,3 +465,57 @@ def test_tickets_are_waitable_one_by_one_in_any_order(engine, depth):
             engine.synchronize()
     finally:
         engine.set_overlap(3)
+
+
+def test_mixed_traffic_matches_serial_runs(engine):
+    """A seeded random mix of everything the lanes support at once: the three kernel builds, batch sizes from one
+    sample to 9 000, erpl_mc_submit_batch and erpl_mc_run_batch interleaved on the same context, waits on single
+    tickets in between, the overlap depth changed on the way, step chunks forced for some batches.  Every batch's
+    summaries and statuses must be, bit for bit, what erpl_mc_run_batch gives for it on an idle context."""
+    rng = np.random.default_rng(20261004)
+    rocket, motor, wm = models.Rocket(), models.LiquidMotor(), models.WindModel()
+    engine.set_config(H.make_config("liquid"))
+    precs = [_abi.PREC_F32, _abi.PREC_F64_FAST, _abi.PREC_F64]
+    pool = []
+    for i in range(9):
+        prec = precs[i % 3]
+        n = int(rng.choice([1, 63, 64, 65, 700, 4000, 9000])) if prec != _abi.PREC_F64 else int(rng.choice([1, 65, 900]))
+        pool.append(sampling.synthetic_dispersions(n, rocket, motor, wm, H.EXAMPLE_IC, engine.device, precision=prec,
+                                                   seed=300 + i, planar=bool(i & 1), engine=engine))
+    engine.set_adopt(0)
+    engine.set_chunk(0)
+    serial = [tuple(x.clone() for x in engine.run(db)) for db in pool]
+    torch.cuda.synchronize()
+    engine.set_adopt(-1)
+    engine.set_chunk(-1)
+    try:
+        pending = []     # (pool index, outputs, ticket or None)
+        for step in range(60):
+            op = rng.random()
+            k = int(rng.integers(len(pool)))
+            if op < 0.55:
+                engine.set_chunk(int(rng.choice([-1, -1, 0, 512])))
+                out = engine.submit(pool[k])
+                pending.append((k, out, engine.last_ticket))
+            elif op < 0.70:
+                out = engine.run(pool[k])                      # on the current stream, lane 0's workspaces
+                pending.append((k, out, None))
+            elif op < 0.85 and pending:
+                j = int(rng.integers(len(pending)))
+                if pending[j][2] is not None:
+                    engine.wait(pending[j][2])
+            elif op < 0.93:
+                engine.set_overlap(int(rng.choice([1, 2, 3, 5, 8])))     # waits for everything in flight
+            else:
+                engine.wait()
+            if len(pending) >= 12 or step == 59:
+                engine.wait()
+                torch.cuda.synchronize()
+                for kk, (s, t), _ in pending:
+                    assert torch.equal(t, serial[kk][1]) and same(s, serial[kk][0]), (step, kk)
+                pending = []
+        engine.synchronize()
+    finally:
+        engine.set_adopt(-1)
+        engine.set_chunk(-1)
+        engine.set_overlap(3)
