@@ -2,11 +2,18 @@
 // (one reciprocal per denominator, interval-record atmosphere, no trig of atan2) carried in double
 // with FMA contraction.  MI355X runs fp64 vector FMAs at half the fp32 rate, so this build keeps
 // fp64 parity with the reference on the chaotic samples at a fraction of the cost
-// of the reference-order gate kernel (erpl_k64.hip).
+// of the reference-order gate kernel (erpl_k64.hip).  Round 3: two waves per SIMD (<= 256 registers
+// per lane: lane state, wind interval and table records in LDS - ERPL_TWO_WAVE in erpl_kernels.inc).
 #define ERPL_REAL double
 #define ERPL_FAITHFUL 0
 #define ERPL_FAST_F32 0
 #define ERPL_FAST_F64 1
+#ifndef ERPL_TWO_WAVE
+#define ERPL_TWO_WAVE 1
+#endif
+#ifndef ERPL_FLIGHT_MIN_WAVES
+#define ERPL_FLIGHT_MIN_WAVES (ERPL_TWO_WAVE ? 2 : 1)
+#endif
 #ifndef ERPL_STAGE_UNROLL
 #define ERPL_STAGE_UNROLL 4
 #endif

@@ -21,4 +21,4 @@ for prec in ("f32", "f64_fast"):
                  "resident_waves_per_simd": best["SQ_WAVE_CYCLES"] * 4.0 / (1024.0 * wall),
                  "note": "largest erpl_flight dispatch of: bench.py --samples-per-gpu 1048576 --overlap 0 (one dense launch)"}
 print(json.dumps(out, indent=1))
-json.dump(out, open(os.path.join(root, "profiles", "r2_pmc_valu_port.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(root, "profiles", sys.argv[2] if len(sys.argv) > 2 else tag + "_pmc_valu_port.json"), "w"), indent=1)
