@@ -7,7 +7,7 @@ been built (run `python -c "import __graft_entry__ as g; g.build()"` or
 import ctypes as C
 import os
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 STATE_DIM = 14
 IC_DIM = 13
 ROCKET_DIM = 2
@@ -34,7 +34,8 @@ FLAG_STOP_AT_APOGEE = 1
  SUM_MAX_SPEED) = range(16)
 
 END_MAX_TIME, END_GROUND, END_ALTITUDE, END_COAST, END_APOGEE = range(5)
-ST_APOGEE_LATCHED, ST_CHUTE, ST_NAN = 1 << 8, 1 << 9, 1 << 10
+ST_APOGEE_LATCHED, ST_CHUTE, ST_NAN, ST_INCOMPLETE = 1 << 8, 1 << 9, 1 << 10, 1 << 11
+ERR_INCOMPLETE = -5
 
 _M = C.c_double * MAX_MACH_KNOTS
 _T = C.c_double * MAX_CURVE_KNOTS
@@ -94,13 +95,19 @@ EXPORTS = ("erpl_mc_abi_version", "erpl_mc_last_error", "erpl_mc_create", "erpl_
            "erpl_mc_kernel_ms_history", "erpl_mc_debug_counters", "erpl_mc_extract_histories", "erpl_mc_set_chunk",
            "erpl_mc_legacy_random_streams", "erpl_mc_legacy_wind_profiles", "erpl_mc_set_waves_per_simd",
            "erpl_mc_set_overlap", "erpl_mc_submit_batch", "erpl_mc_wait_batch", "erpl_mc_synchronize",
-           "erpl_mc_debug_eval", "erpl_mc_synth_wind", "erpl_mc_set_adopt", "erpl_mc_get_overlap")
+           "erpl_mc_debug_eval", "erpl_mc_synth_wind", "erpl_mc_set_adopt", "erpl_mc_get_overlap",
+           "erpl_mc_check_batch", "erpl_mc_set_adopt_spin")
 
 _lib = None
 
 
 class ErplError(RuntimeError):
     pass
+
+
+class IncompleteBatch(ErplError):
+    """A lane hand-over of a batch timed out (ERPL_ERR_INCOMPLETE): the samples whose status word carries
+    ST_INCOMPLETE were not integrated."""
 
 
 def load_library(path=None):
@@ -139,6 +146,8 @@ def load_library(path=None):
                                        C.c_void_p]
     lib.erpl_mc_set_chunk.argtypes = [C.c_void_p, C.c_int]
     lib.erpl_mc_set_adopt.argtypes = [C.c_void_p, C.c_int]
+    lib.erpl_mc_set_adopt_spin.argtypes = [C.c_void_p, C.c_int]
+    lib.erpl_mc_check_batch.argtypes = [C.c_void_p, C.c_int64]
     lib.erpl_mc_get_overlap.argtypes = [C.c_void_p]
     lib.erpl_mc_get_overlap.restype = C.c_int
     lib.erpl_mc_set_waves_per_simd.argtypes = [C.c_void_p, C.c_int]
@@ -165,4 +174,6 @@ def load_library(path=None):
 def check(lib, rc, what):
     if rc != 0:
         msg = lib.erpl_mc_last_error()
+        if rc == ERR_INCOMPLETE:
+            raise IncompleteBatch(f"{what}: {msg.decode() if msg else ''}")
         raise ErplError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

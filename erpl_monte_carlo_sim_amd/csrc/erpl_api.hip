@@ -254,6 +254,7 @@ struct erpl_ctx {
   int64_t submitted = 0;          // tickets handed out
   int last_slot = 0;              // slot of the most recent batch (erpl_mc_last_stats)
   int64_t reserve_n = 0;          // erpl_mc_reserve request, applied to a slot when it is first used
+  int adopt_spin = 1 << 22;       // polls of an adopting lane for a claimed record's ready word (erpl_mc_set_adopt_spin)
   int adopt = -1;                 // lane adoption: flying lanes at or below which a wave hands its lanes over; 0 = off; < 0 = by batch
   int chunk = -1;                 // steps per launch between compactions; 0 = one launch; < 0 = by the batches seen so far
   double seen_mean_steps = 0.0;   // physics RK4 steps per trajectory of the most recent COMPLETED batch
@@ -417,6 +418,7 @@ int enqueue_batch(erpl_ctx* c, int lane, const erpl_batch* b, const erpl_out* o,
   // higher - 24 / 40 / 48 / 56 -> 35.7 / 34.8 / 35.3 / 35.3 ms eight deep, 40.3 / 38.4 / 38.2 / 40.9 three deep)
   if (adopt < 0) adopt = (sweep && hw_queues_env() >= 2 * in_flight + 2) ? (b->precision == ERPL_PREC_F32 ? 24 : 40) : 0;
   a.adopt_lanes = (o->n_traj == 0 && a.chunk_steps == 0) ? adopt : 0;
+  a.adopt_spin = c->adopt_spin;
   if (a.adopt_lanes > 0 && n_phases < 3) n_phases = 3;
   void** ev = c->profiling ? (void**)&c->ev[3 * (c->profiled_runs % ERPL_PROFILE_RING)] : nullptr;
   // with lane adoption the launches behind the main one hold the batch's few longest trajectories: they go to the
@@ -532,6 +534,12 @@ int erpl_mc_set_waves_per_simd(erpl_ctx* c, int waves) {
   return ERPL_OK;
 }
 
+int erpl_mc_set_adopt_spin(erpl_ctx* c, int polls) {
+  if (!c) return fail(ERPL_ERR_INVALID, "null context");
+  c->adopt_spin = polls;
+  return ERPL_OK;
+}
+
 int erpl_mc_set_adopt(erpl_ctx* c, int lanes) {
   if (!c) return fail(ERPL_ERR_INVALID, "null context");
   if (lanes > 63) return fail(ERPL_ERR_INVALID, "adopt lanes must be at most 63");
@@ -605,12 +613,37 @@ int erpl_mc_wait_batch(erpl_ctx* c, int64_t ticket, void* stream) {
       HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, c->slot[i].done, 0));
       exact = true;
     }
-  if (exact) return ERPL_OK;
+  if (!exact)
+    for (int i = 0; i < 2 * ERPL_MAX_OVERLAP; ++i) {
+      ErplSlot& s = c->slot[i];
+      if (!s.used || s.ticket <= 0) continue;
+      if (ticket < 0 || (s.ticket > ticket && (s.ticket - ticket) % c->depth == 0))
+        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, s.done, 0));
+    }
+  // the host does not block here, so only batches that have ALREADY finished can be reported (their counters sit in
+  // pinned memory behind `done`); erpl_mc_check_batch / erpl_mc_synchronize are the blocking checks
   for (int i = 0; i < 2 * ERPL_MAX_OVERLAP; ++i) {
     ErplSlot& s = c->slot[i];
-    if (!s.used || s.ticket <= 0) continue;
-    if (ticket < 0 || (s.ticket > ticket && (s.ticket - ticket) % c->depth == 0))
-      HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, s.done, 0));
+    if (s.used && s.h_counters[3] != 0ull && hipEventQuery(s.done) == hipSuccess)
+      return fail(ERPL_ERR_INCOMPLETE, "lane hand-over timed out in batch %lld: its results are incomplete", (long long)s.ticket);
+  }
+  return ERPL_OK;
+}
+
+int erpl_mc_check_batch(erpl_ctx* c, int64_t ticket) {
+  if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
+  if (ticket > c->submitted) return fail(ERPL_ERR_INVALID, "ticket %lld has not been handed out", (long long)ticket);
+  HIP_TRY(hipSetDevice(c->device));
+  for (int i = 0; i < 2 * ERPL_MAX_OVERLAP; ++i) {
+    ErplSlot& s = c->slot[i];
+    if (!s.used) continue;
+    // (a set reused since then has waited for the batch in question on the device: its own `done` covers it)
+    const bool covers = ticket < 0 || s.ticket == ticket || (s.ticket > ticket && s.ticket > 0 && (s.ticket - ticket) % c->depth == 0);
+    if (!covers) continue;
+    HIP_TRY(hipEventSynchronize(s.done));
+    if (s.h_counters[3] != 0ull && (ticket < 0 || s.ticket == ticket))
+      return fail(ERPL_ERR_INCOMPLETE, "lane hand-over timed out in batch %lld: %llu record(s) lost, their samples carry ERPL_ST_INCOMPLETE",
+                  (long long)s.ticket, (unsigned long long)s.h_counters[3]);
   }
   return ERPL_OK;
 }
@@ -622,7 +655,7 @@ int erpl_mc_synchronize(erpl_ctx* c) {
   if (rc != ERPL_OK) return rc;
   for (int i = 0; i < 2 * ERPL_MAX_OVERLAP; ++i)   // counters of every finished batch sit in pinned memory
     if (c->slot[i].used && c->slot[i].h_counters[3] != 0ull)
-      return fail(ERPL_ERR_HIP, "lane hand-over timed out in batch %lld: its results are incomplete", (long long)c->slot[i].ticket);
+      return fail(ERPL_ERR_INCOMPLETE, "lane hand-over timed out in batch %lld: its results are incomplete", (long long)c->slot[i].ticket);
   return ERPL_OK;
 }
 

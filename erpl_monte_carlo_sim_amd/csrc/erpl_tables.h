@@ -99,6 +99,7 @@ struct ErplKArgs {
   int32_t phase;               // index of this flight launch
   int32_t chunk_steps;         // RK4 steps a lane may take per launch (<= 0: unlimited, one launch)
   int32_t waves_per_simd;      // fp32 flight-kernel build to launch: 2 (256 VGPRs) or 3 (168 VGPRs, spills)
+  int32_t adopt_spin;          // polls an adopting lane waits for a claimed record's ready word (< 0: none - test knob)
   int32_t adopt_lanes;         // > 0: a wave left with at most this many flying lanes once the queue is empty
                                //   parks them in the next phase's queue, where waves that still fly more pick
                                //   them up into their idle lanes (the launcher clears it for the last phase)

@@ -150,7 +150,26 @@ class TrajectoryEngine:
                    "erpl_mc_wait_batch")
 
     def synchronize(self):
+        """Host-blocking wait for everything enqueued; raises _abi.IncompleteBatch if a lane hand-over timed out."""
         _abi.check(self.lib, self.lib.erpl_mc_synchronize(self._ctx), "erpl_mc_synchronize")
+
+    def check(self, ticket=-1):
+        """Where results are consumed: block the host until batch `ticket` (< 0: every submitted batch) has finished
+        and raise _abi.IncompleteBatch if one of its lane hand-overs timed out (erpl_mc_check_batch).  wait() only
+        orders a stream on the device; it reports batches that had ALREADY finished incomplete when it is called."""
+        _abi.check(self.lib, self.lib.erpl_mc_check_batch(self._ctx, int(ticket)), "erpl_mc_check_batch")
+
+    def set_adopt_spin(self, polls):
+        """Test knob (erpl_mc_set_adopt_spin): < 0 makes every adopting lane give up at once."""
+        _abi.check(self.lib, self.lib.erpl_mc_set_adopt_spin(self._ctx, int(polls)), "erpl_mc_set_adopt_spin")
+
+    @staticmethod
+    def raise_if_incomplete(status):
+        """Results whose status words still carry ST_INCOMPLETE were never integrated: refuse to hand them on."""
+        bad = (status & _abi.ST_INCOMPLETE) != 0
+        n_bad = int(bad.sum())
+        if n_bad:
+            raise _abi.IncompleteBatch(f"{n_bad} sample(s) carry ERPL_ST_INCOMPLETE: a lane hand-over timed out")
 
     def debug_eval(self, db, what, inputs):
         """Device-side known-answer evaluation (erpl_mc_debug_eval): inputs [rows, m] -> outputs [rows', m]

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ERPL_MC_ABI_VERSION 2
+#define ERPL_MC_ABI_VERSION 3
 
 #define ERPL_STATE_DIM 14   /* x y z vx vy vz q0(w) q1 q2 q3 wx wy wz propellant_fraction (simulator.py:130) */
 #define ERPL_IC_DIM 13      /* the same without propellant_fraction (always 1.0 at ignition, simulator.py:161) */
@@ -50,7 +50,9 @@ typedef enum erpl_status {
   ERPL_ERR_INVALID = -1,   /* bad argument / shape / non-finite table */
   ERPL_ERR_HIP = -2,       /* a HIP runtime call failed */
   ERPL_ERR_NO_DEVICE = -3, /* no usable GPU: the product path never falls back to a CPU */
-  ERPL_ERR_CONFIG = -4     /* run_batch before set_config */
+  ERPL_ERR_CONFIG = -4,    /* run_batch before set_config */
+  ERPL_ERR_INCOMPLETE = -5 /* a lane hand-over of a finished batch timed out: the samples whose status word still
+                              carries ERPL_ST_INCOMPLETE were not integrated (erpl_mc_set_adopt) */
 } erpl_status;
 
 enum { ERPL_MOTOR_LIQUID = 0, ERPL_MOTOR_SOLID = 1 };
@@ -99,7 +101,11 @@ enum {
   ERPL_END_APOGEE = 4,    /* ERPL_FLAG_STOP_AT_APOGEE */
   ERPL_ST_APOGEE_LATCHED = 1 << 8,
   ERPL_ST_CHUTE = 1 << 9, /* parachute latch set (simulator.py:366-369) */
-  ERPL_ST_NAN = 1 << 10   /* altitude became NaN at some step */
+  ERPL_ST_NAN = 1 << 10,  /* altitude became NaN at some step */
+  ERPL_ST_INCOMPLETE = 1 << 11 /* no result: every status word is set to this value when its batch starts and is
+                              replaced when the trajectory ends; it survives only if a lane hand-over timed out
+                              (a logic error or a wedged wave - never observed), and the summary rows of such
+                              a sample hold only its rail-exit values */
 };
 
 /* Everything shared by all samples of a batch.  Plain attribute values of the reference objects;
@@ -209,8 +215,14 @@ int erpl_mc_set_overlap(erpl_ctx* ctx, int depth);
 int erpl_mc_get_overlap(erpl_ctx* ctx);
 int erpl_mc_submit_batch(erpl_ctx* ctx, const erpl_batch* batch, const erpl_out* out, void* hip_stream, int64_t* ticket);
 int erpl_mc_wait_batch(erpl_ctx* ctx, int64_t ticket, void* hip_stream);
-/* Host-blocking wait for everything this context has enqueued. */
+/* Host-blocking wait for everything this context has enqueued; ERPL_ERR_INCOMPLETE if a lane hand-over of any
+ * batch still on record timed out. */
 int erpl_mc_synchronize(erpl_ctx* ctx);
+/* Where results are consumed: host-blocking wait for batch `ticket` alone (< 0: every batch submitted so far),
+ * then ERPL_OK, or ERPL_ERR_INCOMPLETE if one of its lane hand-overs timed out (its unfinished samples carry
+ * ERPL_ST_INCOMPLETE).  erpl_mc_wait_batch itself never blocks the host and therefore cannot know; it does
+ * report ERPL_ERR_INCOMPLETE for batches that had already finished that way when it is called. */
+int erpl_mc_check_batch(erpl_ctx* ctx, int64_t ticket);
 
 /* Launch geometry knobs (tuning / tests): threads per workgroup (default 64), max workgroups of the
  * persistent flight kernel (0 = library default), lane-refill threshold. */
@@ -241,6 +253,11 @@ int erpl_mc_set_chunk(erpl_ctx* ctx, int chunk_steps);
  * erpl_mc_run_batch (on the caller's one stream a batch is bound by its longest trajectory, which the
  * hand-overs lengthen) and whenever step chunks are in use.  Results do not depend on the value (bitwise). */
 int erpl_mc_set_adopt(erpl_ctx* ctx, int lanes);
+/* Test knob: how often an adopting lane polls for the ready word of the record it has claimed before it gives up
+ * (default 4 194 304 polls of ~0.5 us).  < 0: it gives up at once, published or not - the injected failure of
+ * tests/test_gpu_overlap.py: the record is left alone, its sample keeps ERPL_ST_INCOMPLETE and the batch fails
+ * with ERPL_ERR_INCOMPLETE where it is checked. */
+int erpl_mc_set_adopt_spin(erpl_ctx* ctx, int polls);
 
 /* Diagnostics of the last run_batch on this ctx (after the stream has been synchronised):
  * total RK4 steps integrated over all samples and total wave-iterations executed. */

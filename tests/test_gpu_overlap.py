@@ -519,3 +519,88 @@ def test_mixed_traffic_matches_serial_runs(engine):
         engine.set_adopt(-1)
         engine.set_chunk(-1)
         engine.set_overlap(3)
+
+
+def test_timed_out_hand_over_is_reported_where_results_are_consumed(engine):
+    """A lane hand-over that times out must not pass silently: the adopter leaves the
+    record alone (no stale-id access), the orphaned samples keep ERPL_ST_INCOMPLETE, and the documented flow
+    submit -> erpl_mc_wait_batch -> stream sync sees the failure: erpl_mc_check_batch / erpl_mc_synchronize raise,
+    the next erpl_mc_wait_batch reports the finished batch, and the status words say which samples are missing.
+    The time-out is injected with erpl_mc_set_adopt_spin(-1): every adopting lane gives up at once."""
+    engine.set_config(H.make_config("liquid"))
+    rocket, motor, wm = models.Rocket(), models.LiquidMotor(), models.WindModel()
+    db = sampling.synthetic_dispersions(20000, rocket, motor, wm, H.EXAMPLE_IC, engine.device, precision=_abi.PREC_F64_FAST,
+                                        seed=31, engine=engine)
+    try:
+        engine.set_chunk(0)
+        engine.set_adopt(0)
+        ref_s, ref_t = (x.clone() for x in engine.run(db))
+        torch.cuda.synchronize()
+        assert int(((ref_t & _abi.ST_INCOMPLETE) != 0).sum()) == 0
+        engine.set_overlap(3)
+        engine.set_adopt(24)
+        engine.set_adopt_spin(-1)
+        s, t = engine.submit(db)
+        ticket = engine.last_ticket
+        engine.wait(ticket)                      # device-side order only: cannot know yet
+        torch.cuda.current_stream().synchronize()
+        lost = (t & _abi.ST_INCOMPLETE) != 0
+        n_lost = int(lost.sum())
+        assert n_lost > 0                                   # some record was claimed and dropped
+        assert engine.debug_counters()[3] == n_lost         # one count per dropped record
+        done = ~lost                                        # everything that did finish is untouched by the failure
+        assert torch.equal(t[done], ref_t[done]) and same(s[:, done], ref_s[:, done])
+        with pytest.raises(_abi.IncompleteBatch):
+            engine.check(ticket)
+        with pytest.raises(_abi.IncompleteBatch):
+            engine.wait()                                   # a batch that has already finished incomplete
+        with pytest.raises(_abi.IncompleteBatch):
+            engine.synchronize()
+        with pytest.raises(_abi.IncompleteBatch):
+            engine.raise_if_incomplete(t)
+        # the knob back to its default: the same workspace runs clean again
+        engine.set_adopt_spin(1 << 22)
+        outs = [engine.submit(db) for _ in range(6)]        # (every set of the three lanes is used again)
+        engine.wait()
+        engine.check()
+        engine.synchronize()
+        for s2, t2 in outs:
+            assert torch.equal(t2, ref_t) and same(s2, ref_s)
+    finally:
+        engine.set_adopt_spin(1 << 22)
+        engine.set_adopt(-1)
+        engine.set_chunk(-1)
+        engine.set_overlap(3)
+
+
+def test_soak_every_overlapped_batch_equals_run_batch():
+    """tools/soak_adopt.py as a (short) test: full-size batches eight deep with lane adoption and its sweep
+    launches on, every batch compared bit for bit with erpl_mc_run_batch of the same inputs (round 2 ran 696
+    such batches in the tool: 0 differ)."""
+    from erpl_monte_carlo_sim_amd.engine import TrajectoryEngine
+    eng = TrajectoryEngine(torch.device("cuda", 0))
+    try:
+        eng.set_config(H.make_config("liquid"))
+        rocket, motor, wm = models.Rocket(), models.LiquidMotor(), models.WindModel()
+        for precision, n, rounds in (("f64_fast", 131072, 2), ("f32", 131072, 3)):
+            prec = _abi.PRECISIONS[precision]
+            dbs = [sampling.synthetic_dispersions(n - 4099 * i, rocket, motor, wm, H.EXAMPLE_IC, eng.device, precision=prec,
+                                                  seed=1234 + i, engine=eng) for i in range(2)]
+            eng.set_adopt(0)
+            refs = [tuple(x.clone() for x in eng.run(db)) for db in dbs]
+            torch.cuda.synchronize()
+            eng.set_adopt(-1)
+            depth = eng.get_overlap()
+            eng.set_overlap(depth)
+            bad = total = 0
+            for r in range(rounds):
+                k = r % 2
+                outs = [eng.submit(dbs[k]) for _ in range(depth)]
+                eng.wait()
+                eng.check()
+                for s, t in outs:
+                    bad += 0 if (torch.equal(t, refs[k][1]) and same(s, refs[k][0])) else 1
+                    total += 1
+            assert bad == 0, (precision, bad, total)
+    finally:
+        eng.close()
