@@ -6,10 +6,15 @@
 
 One "step" = one pass of the hot path (rail kernel + RK4 flight kernel [+ RCCL all-gather of the
 per-sample summaries when N > 1]) over one batch of synthetic dispersions ALREADY RESIDENT in HBM.
-Workload at N = 1: the fp32 throughput configuration (BASELINE configs[2]/[3]): 131 072 dispersed
-samples per GPU (x 8 GPUs = the 1 048 576 samples of configs[3]), LiquidMotor, reference
-dispersion model (monte_carlo.py:156-179), synthetic 100-knot wind profile, full reference
-termination logic.  Weak scaling: every rank integrates its own 131 072-sample shard.
+Workload at N = 1: 131 072 dispersed samples per GPU (BASELINE configs[2]; x 8 GPUs = the 1 048 576
+samples of configs[3]), LiquidMotor, reference dispersion model (monte_carlo.py:156-179), synthetic
+100-knot wind profile, full reference termination logic.  Weak scaling (default): every rank integrates its
+own 131 072-sample shard; `--total-samples N` splits a fixed N over the ranks instead (strong scaling:
+configs[3]'s 1 048 576 at 1 / 2 / 4 / 8 GPUs).
+
+The headline leg is the fp64 throughput build (ERPL_PREC_F64_FAST): it is the build that meets north_star's
+"per-sample apogee within 0.1 %" (apogee_match_rate 0.998; the fp32 build, which configs[2] names, reproduces
+the reference's apogee_altitude on 17 % of these samples and is reported as the secondary `f32` leg).
 
 Passes are handed to the library with erpl_mc_submit_batch: up to `--overlap` of them are in flight
 on the library's internal streams (a pass over a batch that just fills the GPU lasts as long as its
@@ -17,7 +22,7 @@ longest trajectory; the next pass uses the lanes that have already finished).  A
 inside the timed region.
 
 Prints ONE JSON line (rank 0).  `value`, `dtype`, `apogee_match_rate`, `roofline` all describe the SAME
-kernel build (--precision, default f32) on the SAME shard:
+kernel build (--precision, default f64_fast) on the SAME shard:
   apogee_match_rate  fraction of the shard's samples whose `apogee_altitude` (the reference's global
                 argmax, simulator.py:488-490) is within 0.1 % of the fp64 reference-order gate kernel
                 run on the same inputs (that kernel tracks the CPU oracle on 100 % of the cfg-2 set:
@@ -30,8 +35,10 @@ kernel build (--precision, default f32) on the SAME shard:
                 `overlap` launches in flight a dispatch lasts about `overlap` times the time per launch.
   cpu_baseline  the CPU oracle (C fp64 restatement, OpenMP over samples, all host cores) on a
                 bounded sample of the same shard; a reported baseline, not the target.
-  f64_fast      the same K passes with the ERPL_PREC_F64_FAST build (fp64 arithmetic, short
-                formulation): its own value / apogee_match_rate / roofline triple.
+  f32           the same K passes with the ERPL_PREC_F32 build: its own value / apogee_match_rate / roofline.
+  cfg5_share    BASELINE configs[4]'s per-GPU share (1.25 M samples, CSV wind + parachute, full flights) in the
+                headline build, with its 256-sample oracle subset (outside the headline timed region).
+  api_end_to_end  MonteCarloAnalyzer.run_monte_carlo / run_monte_carlo_device at 10^6 samples.
 """
 import argparse
 import json
@@ -129,6 +136,94 @@ def host_slice(db, m):
     return hb
 
 
+def cfg5_share(eng, device, rocket, atm, wm, args, n=1250000, passes=2, subset=256):
+    """BASELINE configs[4] ("10M samples, CSV wind profile + parachute-deploy event detection, 8xMI355X with per-GPU
+    compaction"): one GPU's share - 1.25 M samples, CSV base wind, full flights to the ground under the parachute -
+    in the headline (fp64 throughput) build with the library's automatic step chunks, outside the headline timed
+    region.  The first `subset` samples are also run through the CPU oracle: landing and parachute latch must agree."""
+    from oracle import oracle as orc
+    motor = models.LiquidMotor()
+    cfg5 = flatten.config_from_objects(rocket, motor, atm)
+    eng.set_config(cfg5)
+    db = sampling.synthetic_dispersions(n, rocket, motor, wm, EXAMPLE_IC, device, precision=_abi.PREC_F64_FAST, seed=4321,
+                                        planar=True, base_altitude_profile=CSV_ALT, base_wind_profile=CSV_WIND, engine=eng)
+    depth = eng.get_overlap()
+    eng.set_overlap(depth)
+    outs = [eng.alloc_outputs(n) for _ in range(2)]
+    for i in range(2):          # the library learns the trajectory length from finished batches (automatic step chunks)
+        eng.submit(db, summary=outs[i % 2][0], status=outs[i % 2][1])
+        eng.wait()
+        torch.cuda.synchronize()
+    # `passes` batches in flight together (another batch fills every chunk barrier), as a 10 M-sample run would submit them
+    outs = [eng.alloc_outputs(n) for _ in range(passes)]
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    for i in range(passes):
+        eng.submit(db, summary=outs[i][0], status=outs[i][1])
+    eng.wait()
+    ev1.record()
+    torch.cuda.synchronize()
+    eng.synchronize()
+    ms = ev0.elapsed_time(ev1) / passes
+    steps, wi = eng.last_stats()
+    summ, status = outs[-1]
+    st = status.cpu().numpy()
+    tf = steps * FLOPS_PER_STEP / (ms * 1e-3) / 1e12
+    hb = host_slice(db, subset)
+    osum, ostat = orc.run_batch(cfg5, hb, threads=host_cores())
+    gs, gt = summ[:, :subset].cpu().numpy(), st[:subset]
+    rep = match_report(osum, ostat, gs, gt)
+    rep.pop("by_reference_class")
+    landed_ref = (ostat & 0xFF) == 1
+    rep["oracle_landed_under_parachute"] = int(np.sum(landed_ref & ((ostat & _abi.ST_CHUTE) != 0)))
+    rep["same_landing_and_parachute_latch"] = float(np.mean(((gt & 0xFF) == (ostat & 0xFF)) &
+                                                            ((gt & _abi.ST_CHUTE) == (ostat & _abi.ST_CHUTE))))
+    return {
+        "workload": f"{n} samples (BASELINE configs[4] / 8 GPUs), planar dispersions, CSV base wind K=6 + AR(1) turbulence, "
+                    f"full flights with parachute latch, f64_fast, automatic step chunks, {passes} batches in flight",
+        "value": n / ms * 1e3, "unit": "trajectories/s", "ms_per_pass": ms, "dtype": "f64_fast",
+        "steps_per_trajectory_mean": steps / n, "lane_utilisation": steps / (64.0 * wi) if wi else None,
+        "roofline": {"bound": "valu", "achieved": tf, "peak": PEAK_TFLOPS["f64_fast"], "unit": "TFLOP/s",
+                     "frac": tf / PEAK_TFLOPS["f64_fast"], "kernel": "erpl_flight_f64f", "rk4_steps_per_launch": steps},
+        "end_reasons": {k: int(np.sum((st & 0xFF) == v)) for k, v in
+                        (("max_time", 0), ("ground", 1), ("altitude_100km", 2), ("coast", 3), ("apogee", 4))},
+        "parachute_deployed": int(np.sum((st & _abi.ST_CHUTE) != 0)),
+        "landed_under_parachute_fraction": float(np.mean(((st & 0xFF) == 1) & ((st & _abi.ST_CHUTE) != 0))),
+        "oracle_subset": {"n": subset, **rep},
+    }
+
+
+def api_end_to_end(device, rocket, motor, atm, wm, n=1000000):
+    """The named API end to end at BASELINE size (outside the timed region): run_monte_carlo_device (dispersions drawn
+    on the device, sub-batches overlapped, statistics on the device) and run_monte_carlo (the reference-exact drop-in:
+    per-sample MT19937 streams on the host, chunked pipeline, lazy result records; monte_carlo.py:52-90)."""
+    import erpl_monte_carlo_sim_amd as E
+    mc = E.MonteCarloAnalyzer(rocket, motor, atm, wm, device=device, verbose=False)
+    out = {"n_samples": n}
+    for precision in ("f64_fast", "f32"):
+        mc.run_monte_carlo_device(dict(EXAMPLE_IC), n, precision=precision)      # warm-up (allocations, first launches)
+        r = mc.run_monte_carlo_device(dict(EXAMPLE_IC), n, precision=precision)
+        out["run_monte_carlo_device_" + precision] = {**r["performance"], "n_valid": r["n_samples"], "n_outliers": r["n_outliers"]}
+    for precision, m in (("f64_fast", n), ("f64", 50000)):
+        mc.precision = precision
+        t1 = time.perf_counter()
+        try:
+            res = mc.run_monte_carlo(dict(EXAMPLE_IC), n_samples=m)
+            shape = {"n_valid": res["n_samples"], "n_outliers": res["n_outliers"]}
+            t2 = time.perf_counter()
+            first = res["results"][0]
+            shape["first_record_ms"] = (time.perf_counter() - t2) * 1e3
+            shape["record_keys"] = len(first)
+        except ValueError as e:      # the reference's own behaviour when no sample survives the outlier rules
+            shape = {"raised": str(e)[:60]}
+        el = (t2 if "n_valid" in shape else time.perf_counter()) - t1
+        out["run_monte_carlo_" + precision] = {"n_samples": m, "total_time": el, "simulations_per_second": m / el, **shape}
+    out["note"] = ("run_monte_carlo defaults to precision 'f64' (the reference-order gate kernel: 100 % of the reference's "
+                   "outcomes); 'f64_fast' is the build for 10^5 - 10^7 samples (99.7-99.9 %)")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,10 +232,14 @@ def main():
     ap.add_argument("--samples-per-gpu", type=int, default=131072)
     ap.add_argument("--workload", default="set_s", choices=["set_s", "set_p_apogee", "set_p_full", "csv_chute"])
     ap.add_argument("--motor", default="liquid", choices=["liquid", "solid"])
-    ap.add_argument("--precision", default="f32", choices=["f32", "f64", "f64_fast"])
+    ap.add_argument("--precision", default="f64_fast", choices=["f32", "f64", "f64_fast"])
+    ap.add_argument("--total-samples", type=int, default=0,
+                    help="strong scaling: split this many samples over the ranks (0 = weak scaling, --samples-per-gpu each)")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the cfg5_share block")
+    ap.add_argument("--no-api", action="store_true", help="skip the api_end_to_end block")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--no-second-leg", action="store_true", help="skip the f64_fast leg")
+    ap.add_argument("--no-second-leg", action="store_true", help="skip the secondary leg (f32 beside f64_fast and vice versa)")
     ap.add_argument("--block", type=int, default=0, help="threads per workgroup (0 = library default)")
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--refill", type=int, default=1)
@@ -188,20 +287,13 @@ def main():
     lib_depth = eng.get_overlap()     # 8 when the process has a hardware queue per batch in flight, else 3
 
     def leg_depth(precision):
-        """Passes in flight for a leg.  All K passes finish inside the timed region, so the pipeline's fill and
-        drain count.  Identical passes submitted together run in step and finish in rounds of `depth`; a last,
-        partial round has the GPU to itself at low occupancy.  The fp32 leg therefore takes the largest depth from
-        4 to the library's that divides K (K = 20: five deep 10.8 ms per pass, six 11.7, eight 11.0; steady state
-        9.45 eight deep); the one-wave-per-SIMD fp64 kernels are fastest eight deep whatever K."""
-        if args.overlap >= 0:
-            return args.overlap
-        if precision == "f32":
-            full_rounds = [d for d in range(4, lib_depth + 1) if args.steps % d == 0]
-            return max(full_rounds) if full_rounds else lib_depth
-        return lib_depth
+        """Passes in flight for a leg: the library's own default (8 with a hardware queue per stream, else 3) unless
+        --overlap says otherwise.  All K passes finish inside the timed region, so the pipeline's fill and drain count."""
+        return args.overlap if args.overlap >= 0 else lib_depth
 
     depth = leg_depth(args.precision)
-    n = args.samples_per_gpu
+    n = -(-args.total_samples // world) if args.total_samples > 0 else args.samples_per_gpu
+    scaling = "strong" if args.total_samples > 0 else "weak"
     planar = args.workload.startswith("set_p")
     flags = _abi.FLAG_STOP_AT_APOGEE if args.workload == "set_p_apogee" else 0
     csv = args.workload == "csv_chute"
@@ -219,8 +311,12 @@ def main():
         depth = leg_depth(precision)
         if depth > 0:
             eng.set_overlap(depth)
-        nbuf = max(depth, 1) + (1 if world > 1 else 0)
+        # every lane of the library owns two workspaces (a lane's next batch starts while the sweeps of its previous one
+        # still write results): pass i + depth may run beside pass i, so the output buffers rotate over 2 x depth sets
+        # (+ 1 for the gather that still reads one) - a buffer is reused only behind the batch that last wrote it
+        nbuf = 2 * max(depth, 1) + (1 if world > 1 else 0)
         outs = [eng.alloc_outputs(n) for _ in range(nbuf)]
+        last_ticket_of = [0] * nbuf
         gath = []
         for _ in range(nbuf if world > 1 else 0):
             gdev = "cpu" if gloo_rehearsal else device
@@ -239,7 +335,10 @@ def main():
             wait_gather(k)  # the gather that last read these output buffers
             s_k, t_k = outs[k]
             if depth > 0:
+                if last_ticket_of[k]:
+                    eng.wait(last_ticket_of[k])   # (device-side; a no-op in practice: that batch is 2 x depth passes back)
                 eng.submit(db, flags=flags, summary=s_k, status=t_k)
+                last_ticket_of[k] = eng.last_ticket
             else:
                 eng.run(db, flags=flags, summary=s_k, status=t_k)
             if world > 1:
@@ -284,6 +383,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         gpu_ms = ev0.elapsed_time(ev1)
+        eng.synchronize()     # raises if a lane hand-over of any pass timed out (its samples would carry ST_INCOMPLETE)
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo_rehearsal else device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -323,11 +423,11 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
         # (FETCH_SIZE / WRITE_SIZE need the profiler, they cannot be read from inside this process)
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r3_hbm_traffic.json")
         if os.path.exists(tpath) and args.workload == "set_s" and n == 131072:
             tj = json.load(open(tpath)).get(precision)
             if tj:
-                traffic, traffic_src = tj.get("traffic_bytes_per_launch"), "profiles/r2_hbm_traffic.json (rocprofv3 --pmc passes of this command)"
+                traffic, traffic_src = tj.get("traffic_bytes_per_launch"), "profiles/r3_hbm_traffic.json (rocprofv3 --pmc passes of this command)"
         st = L["status"].cpu().numpy()
         steps_col = L["summary"][_abi.SUM_STEPS].cpu().numpy()
         return {
@@ -348,6 +448,7 @@ def main():
                 "kernel": "erpl_flight_" + {"f32": "f32", "f64": "f64", "f64_fast": "f64f"}[precision],
                 "algorithmic_flops_per_step": FLOPS_PER_STEP, "rk4_steps_per_launch": L["phys_steps"],
                 "launch_duration_ms": per_launch_ms,
+                "timeline": "profiles/r3_bench_timeline.json (rocprofv3 --kernel-trace of this command: union of the erpl_flight dispatch intervals / passes)",
                 "per_dispatch": {"duration_ms": fl, "achieved": dispatch_tf, "frac": dispatch_tf / peak,
                                  "note": "what rocprofv3 --kernel-trace reports per dispatch; dispatches overlap"},
                 "note": "non-MFMA vector-ALU bound (SURVEY 8d); peak = vector rate of the dtype",
@@ -358,8 +459,9 @@ def main():
 
     main_leg = timed_leg(args.precision)
     second = None
-    if not args.no_second_leg and args.precision != "f64_fast":
-        second = timed_leg("f64_fast")
+    second_name = {"f64_fast": "f32", "f32": "f64_fast", "f64": "f64_fast"}[args.precision]
+    if not args.no_second_leg:
+        second = timed_leg(second_name)
 
     out = None
     if rank == 0:
@@ -368,7 +470,7 @@ def main():
         body = leg_json(main_leg)
         out.update({"value": body.pop("value"), "unit": body.pop("unit"), "n_gpus": world, "steps": args.steps,
                     "warmup": args.warmup, "ms_per_step": body.pop("ms_per_step"), "higher_is_better": True,
-                    "scaling": "weak", "vs_baseline": None, "dtype": body.pop("dtype"), "data": "synthetic",
+                    "scaling": scaling, "vs_baseline": None, "dtype": body.pop("dtype"), "data": "synthetic",
                     "config": {
                         "workload": f"{args.workload}: {n} dispersed 6-DOF samples/GPU ({total_traj} total), "
                                     f"{args.motor} motor, reference dispersion model, "
@@ -381,7 +483,10 @@ def main():
                     }})
         out.update(body)
         if second is not None:
-            out["f64_fast"] = leg_json(second)
+            out[second_name] = leg_json(second)
+            if second_name == "f32":
+                out["f32"]["note"] = ("BASELINE configs[2] names fp32; it is the secondary leg because it does not reproduce the "
+                                      "reference's apogee_altitude on diverging samples (see its apogee_match_rate; DESIGN.md section 5)")
 
     # ---------------- parity + CPU baseline (N = 1 only, rank 0, outside the timed region) ----------------
     if rank == 0 and world > 1:
@@ -407,8 +512,8 @@ def main():
         out["parity"] = {"timed_shard_vs_fp64_gate_kernel": rep}
         if second is not None:
             rep2 = match_report(gs, gt, second["summary"].cpu().numpy(), second["status"].cpu().numpy())
-            out["f64_fast"]["apogee_match_rate"] = rep2["apogee_match_rate_0p1pct"]
-            out["f64_fast"]["parity"] = {"timed_shard_vs_fp64_gate_kernel": rep2}
+            out[second_name]["apogee_match_rate"] = rep2["apogee_match_rate_0p1pct"]
+            out[second_name]["parity"] = {"timed_shard_vs_fp64_gate_kernel": rep2}
     if rank == 0 and world == 1 and (args.cpu_seconds > 0 or not args.no_parity):
         from oracle import oracle as orc
         cores = host_cores()
@@ -437,7 +542,7 @@ def main():
                 "note": "physics_steps_per_s is the unit of the GPU's trajectory_steps_per_s; all_loop_steps_per_s also counts the no-op steps of non-finite trajectories the oracle runs to max_time",
             }
             if not args.no_parity:
-                for L, dst in ((main_leg, out), (second, out.get("f64_fast"))):
+                for L, dst in ((main_leg, out), (second, out.get(second_name))):
                     if L is None:
                         continue
                     got_s, got_t = L["summary"][:, :m].cpu().numpy(), L["status"][:m].cpu().numpy()
@@ -459,31 +564,11 @@ def main():
                 res[name] = r
             out["parity"]["cfg2_set_r_1k_vs_cpu_oracle"] = res
             eng.set_config(cfg)
-    if rank == 0 and world == 1 and not args.no_parity and args.workload == "set_s":
-        # the named API end to end (generate on the device + integrate + statistics), outside the timed region
-        import erpl_monte_carlo_sim_amd as E
-        mc = E.MonteCarloAnalyzer(rocket, motor, atm, wm, device=device, verbose=False)
-        api = {}
-        for precision in ("f64_fast", "f32"):
-            mc.run_monte_carlo_device(dict(EXAMPLE_IC), n, precision=precision)      # warm-up (allocations, first launches)
-            r = mc.run_monte_carlo_device(dict(EXAMPLE_IC), n, precision=precision)
-            api[precision] = {k: r["performance"][k] for k in ("simulations_per_second", "total_time", "generate_s",
-                                                               "integrate_and_gather_s", "statistics_s")}
-            api[precision]["n_valid"], api[precision]["n_outliers"] = r["n_samples"], r["n_outliers"]
-        out["api_end_to_end"] = {"call": f"MonteCarloAnalyzer.run_monte_carlo_device(ic, {n}, precision=...)", **api}
-        # the reference-exact drop-in: per-sample MT19937 streams on the host, list-of-dicts results (monte_carlo.py:52-90)
-        m_host = 20000
-        for precision in ("f64_fast", "f64"):
-            mc.precision = precision
-            t1 = time.perf_counter()
-            try:
-                res = mc.run_monte_carlo(dict(EXAMPLE_IC), n_samples=m_host)
-                shape = {"n_valid": res["n_samples"], "n_outliers": res["n_outliers"]}
-            except ValueError as e:      # the reference's own behaviour when no sample survives the outlier rules
-                shape = {"raised": str(e)[:60]}
-            el = time.perf_counter() - t1
-            out["api_end_to_end"]["run_monte_carlo_" + precision] = {"n_samples": m_host, "total_time": el,
-                                                                    "simulations_per_second": m_host / el, **shape}
+    if rank == 0 and world == 1 and not args.no_cfg5 and args.workload == "set_s" and args.samples_per_gpu == 131072:
+        out["cfg5_share"] = cfg5_share(eng, device, rocket, atm, wm, args)
+        eng.set_config(cfg)
+    if rank == 0 and world == 1 and not args.no_api and args.workload == "set_s":
+        out["api_end_to_end"] = api_end_to_end(device, rocket, motor, atm, wm)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -2,10 +2,30 @@
 smcconoughey/erpl_monte_carlo_sim: MonteCarloAnalyzer.run_monte_carlo / FlightSimulator.simulate_flight).
 """
 import os as _os
+import sys as _sys
+
+
+def _hip_already_started():
+    t = _sys.modules.get("torch")
+    try:
+        return bool(t is not None and t.cuda.is_initialized())
+    except Exception:
+        return False
+
 
 # Eight batches in flight need a hardware queue each (include/erpl_mc.h, erpl_mc_set_overlap); the HIP
-# runtime reads the limit once, at its first call - which a bare `import torch` has not made yet.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+# runtime reads the limit once, at its first call - which a bare `import torch` has not made yet.  If the
+# runtime is already up (the caller used torch.cuda before importing this package, or a profiler preloaded it)
+# the variable is left alone: the library sizes its overlap depth from it and must not believe in queues the
+# process does not have (measured: eight lanes on four queues are 2x slower than three).
+if "GPU_MAX_HW_QUEUES" not in _os.environ:
+    if _hip_already_started():
+        import warnings as _warnings
+        _warnings.warn("HIP was initialised before erpl_monte_carlo_sim_amd was imported: GPU_MAX_HW_QUEUES stays at the "
+                       "runtime's default (4 hardware queues), so submitted batches overlap three deep instead of eight. "
+                       "Import this package (or export GPU_MAX_HW_QUEUES=24) before the first torch.cuda call.")
+    else:
+        _os.environ["GPU_MAX_HW_QUEUES"] = "24"
 
 from .models import Rocket, SolidMotor, LiquidMotor, StandardAtmosphere, WindModel  # noqa: F401
 

@@ -149,4 +149,7 @@ def device_statistics(summary, status=None):
                                      enumerate(("max_time", "ground_impact", "excessive_altitude",
                                                 "coast_timeout", "apogee"))}
         out["n_non_finite"] = int(((status.to(torch.int64) & _abi.ST_NAN) != 0).sum().item())
+        n_inc = int(((status.to(torch.int64) & _abi.ST_INCOMPLETE) != 0).sum().item())
+        if n_inc:   # a lane hand-over timed out: these samples were never integrated (include/erpl_mc.h)
+            raise _abi.IncompleteBatch(f"{n_inc} sample(s) carry ERPL_ST_INCOMPLETE: refusing to compute statistics on them")
     return out

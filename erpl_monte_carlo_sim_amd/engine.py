@@ -46,7 +46,9 @@ class DeviceBatch:
             raise _abi.ErplError(f"{hb.k_wind} wind knots exceed the ABI limit {_abi.MAX_WIND_KNOTS}")
         if hb.k_wind and not np.all(np.diff(hb.alt_grid) > 0):
             raise _abi.ErplError("altitude_profile must be strictly increasing")
-        if hb.k_wind and not (np.all(np.isfinite(hb.wind)) and np.all(np.isfinite(hb.alt_grid))):
+        # (one reduction instead of an element-wise mask: a NaN or inf anywhere makes the sum non-finite; a finite table
+        # whose sum overflows is re-checked element by element)
+        if hb.k_wind and not (np.all(np.isfinite(hb.alt_grid)) and (np.isfinite(np.sum(hb.wind)) or np.all(np.isfinite(hb.wind)))):
             raise _abi.ErplError("wind profile must be finite")
         # The kernels assume what the reference silently assumes: finite inputs, positive masses and
         # mass flow, a finite burn time (a non-finite burn time would never leave the launch rail).

@@ -294,11 +294,17 @@ def legacy_streams(seeds, ops, threads=0, by_output=False):
     return out
 
 
-def generate_parameter_arrays(uncertainty, n_samples):
-    """monte_carlo.py:156-179 for samples 0..n-1 (RandomState(i) each) as arrays: dict of [n, 3] /
+def generate_parameter_arrays(uncertainty, n_samples, stream="seed_i"):
+    """monte_carlo.py:156-179 for samples 0..n-1 (`stream='seed_i'`: RandomState(i) each) or :181-201
+    (`stream='seed_42'`: ONE RandomState(42) stream drawn sample after sample) as arrays: dict of [n, 3] /
     [n] float64 plus "random_seed"."""
     u = uncertainty
-    r = legacy_streams(np.arange(n_samples, dtype=np.uint32), _PARAM_OPS)
+    if stream == "seed_42":   # the same 17 draws per sample, continued on one generator (the polar method's cached
+        # second normal carries over from sample to sample exactly as in the reference's loop)
+        r = legacy_streams(np.array([42], dtype=np.uint32), _PARAM_OPS * n_samples).reshape(n_samples, len(_PARAM_OPS)) \
+            if n_samples else np.empty((0, len(_PARAM_OPS)))
+    else:
+        r = legacy_streams(np.arange(n_samples, dtype=np.uint32), _PARAM_OPS)
     sc = lambda key: np.asarray(u[key], dtype=np.float64)[None, :]
     lo_s, hi_s = u["wind_speed_range"]
     lo_d, hi_d = u["wind_direction_range"]
@@ -325,9 +331,7 @@ def generate_parameter_samples(uncertainty, n_samples, stream="seed_i"):
     """The dispersion draws of monte_carlo.py:156-179 (`stream='seed_i'`: RandomState(i) per
     sample) or :181-201 (`stream='seed_42'`: one RandomState(42) stream) as the reference's list of
     per-sample dicts, bit-identical to the reference's values."""
-    if stream == "seed_42":   # one sequential stream: nothing to spread over samples
-        return generate_parameter_samples_loop(uncertainty, n_samples, stream)
-    return _arrays_to_params(generate_parameter_arrays(uncertainty, n_samples))
+    return _arrays_to_params(generate_parameter_arrays(uncertainty, n_samples, stream))
 
 
 def params_to_arrays(params_list):

@@ -15,11 +15,20 @@ import numpy as np
 import torch
 
 from . import _abi, analysis, dist, flatten, reports
-from .engine import DeviceBatch
+from . import results as results_mod
+from .engine import DeviceBatch, TrajectoryEngine
 from .sampling import DEFAULT_UNCERTAINTY
 from .simulator import shared_engine
 
-_END = ("max_time", "ground_impact", "excessive_altitude", "coast_timeout", "apogee")
+_END = results_mod.END_NAMES
+
+
+class _Shard:
+    """Stand-in for a HostBatch in dist.run_local_shard: only its size is looked at (the shard is built chunk by
+    chunk inside the runner)."""
+
+    def __init__(self, n):
+        self.n = n
 
 
 class MonteCarloAnalyzer:
@@ -52,36 +61,51 @@ class MonteCarloAnalyzer:
                                            max_time=self.max_time, pitch_damping=self.pitch_damping,
                                            yaw_damping=self.yaw_damping)
 
-    def _gpu_runner(self, n_traj_global, lo):
-        """runner(HostBatch of this rank's shard) for dist.run_local_shard.  The samples that carry a
-        trajectory (global index < n_traj_global: the first ones of the shard) go through the
-        trajectory-capture build in a small batch of their own; everything else runs through the
-        specialised non-capturing build (which also fast-forwards non-finite trajectories).  Samples are
-        independent, so the split does not change a single bit of the summaries (tested)."""
+    CHUNK = 131072   # samples per submitted batch: one batch fills an MI355X (256 CUs x 4 SIMDs x 2 waves x 64 lanes)
+
+    def _integrate_shard(self, initial_conditions, params, lo, hi, n_traj_global):
+        """Integrate samples [lo, hi) of `params` (dict of arrays or list of dicts) on this rank's GPU; returns
+        (summary [16, hi-lo] device tensor, status [hi-lo] device tensor, captured trajectories or None).
+
+        The samples that carry a trajectory (global index < n_traj_global: the first ones of the shard) go through
+        the trajectory-capture build in a small batch of their own; everything else runs in chunks of CHUNK samples
+        handed to erpl_mc_submit_batch, so that the host builds chunk i+1 (MT19937 streams and AR(1) wind tables in
+        C threads, the rest as NumPy expressions) while the GPU integrates chunk i.  Samples are independent: the
+        split does not change a single bit of the summaries (tested)."""
         eng = shared_engine(self.device)
         eng.set_config(self._config())
         prec = _abi.PRECISIONS[self.precision]
-        box = {}
+        take = (lambda a, b: {k: v[a:b] for k, v in params.items()}) if isinstance(params, dict) else (lambda a, b: params[a:b])
 
-        def runner(hb):
-            m = max(0, min(hb.n, n_traj_global - lo))   # local samples 0..m-1 are captured
-            parts = []
-            if m > 0:
-                head = hb.take(np.arange(m)) if m < hb.n else hb
-                db = DeviceBatch.from_host(head, eng.device, prec)
-                dt = min(self.dt_initial, 0.005)
-                cap = int(np.ceil(self.max_time / dt / self.trajectory_stride)) + 4
-                ids = list(range(m))
-                summ, status, traj, tlen = eng.run(db, traj_ids=ids, traj_stride=self.trajectory_stride, traj_cap=cap)
-                box["traj"] = (ids, traj, tlen)
-                parts.append((summ, status))
-            if m < hb.n:
-                tail = hb.take(np.arange(m, hb.n)) if m > 0 else hb
-                parts.append(eng.run(DeviceBatch.from_host(tail, eng.device, prec)))
-            if len(parts) == 1:
-                return parts[0]
-            return torch.cat([p[0] for p in parts], dim=1), torch.cat([p[1] for p in parts])
-        return runner, box
+        def host_batch(a, b):
+            return flatten.dispersed_batch(self.rocket, self.motor, self.wind_model, initial_conditions, take(a, b),
+                                           self.base_altitude_profile, self.base_wind_profile)
+        parts, traj = [], None
+        m = max(0, min(hi, n_traj_global) - lo)   # local samples 0..m-1 are captured
+        if m > 0:
+            db = DeviceBatch.from_host(host_batch(lo, lo + m), eng.device, prec)
+            dt = min(self.dt_initial, 0.005)
+            cap = int(np.ceil(self.max_time / dt / self.trajectory_stride)) + 4
+            ids = list(range(m))
+            summ, status, tr, tlen = eng.run(db, traj_ids=ids, traj_stride=self.trajectory_stride, traj_cap=cap)
+            traj = (ids, tr, tlen)
+            parts.append((summ, status))
+        inflight = []    # (ticket, inputs): the inputs must outlive their batch (it runs on the library's own streams)
+        keep = 2 * eng.get_overlap() + 1
+        for a in range(lo + m, hi, self.CHUNK):
+            b = min(hi, a + self.CHUNK)
+            db = DeviceBatch.from_host(host_batch(a, b), eng.device, prec)
+            parts.append(eng.submit(db))
+            inflight.append((eng.last_ticket, db))
+            if len(inflight) > keep:
+                eng.check(inflight[0][0])   # host-blocking, and raises if a lane hand-over of that batch timed out
+                inflight.pop(0)
+        if inflight:
+            eng.wait()
+            eng.check()
+        if len(parts) == 1:
+            return parts[0][0], parts[0][1], traj
+        return torch.cat([p[0] for p in parts], dim=1), torch.cat([p[1] for p in parts]), traj
 
     def run_batch_arrays(self, initial_conditions, parameter_samples):
         """Integrate the given dispersed samples; returns (summary [16, n], status [n]) NumPy arrays
@@ -91,69 +115,63 @@ class MonteCarloAnalyzer:
         n = len(parameter_samples["random_seed"]) if isinstance(parameter_samples, dict) else len(parameter_samples)
         rank, ws = dist.world()
         lo, hi, _ = dist.shard_bounds(n, rank, ws)
-        if isinstance(parameter_samples, dict):
-            mine = {k: v[lo:hi] for k, v in parameter_samples.items()}
-        else:
-            mine = parameter_samples[lo:hi]
-        hb = flatten.dispersed_batch(self.rocket, self.motor, self.wind_model, initial_conditions,
-                                     mine, self.base_altitude_profile, self.base_wind_profile) if hi > lo else None
-        runner, box = self._gpu_runner(min(self.n_trajectories, n), lo)
-        summ, status = dist.run_local_shard(n, hb, runner)
+        box = {}
+
+        def runner(_unused):
+            summ, status, box["traj"] = self._integrate_shard(initial_conditions, parameter_samples, lo, hi,
+                                                              min(self.n_trajectories, n))
+            return summ, status
+        local = _Shard(hi - lo) if hi > lo else None
+        summ, status = dist.run_local_shard(n, local, runner)
+        TrajectoryEngine.raise_if_incomplete(status)
         return summ, status, box.get("traj"), lo
 
-    def _result_dicts(self, summ, status, parameter_samples, traj, lo):
-        cols = {name: summ[row].tolist() for name, row in (
-            ("apogee_altitude", _abi.SUM_APOGEE_ALT), ("apogee_time", _abi.SUM_APOGEE_TIME), ("range", _abi.SUM_RANGE),
-            ("flight_time", _abi.SUM_FLIGHT_TIME), ("rail_exit_time", _abi.SUM_RAIL_EXIT_TIME),
-            ("rail_exit_speed", _abi.SUM_RAIL_EXIT_SPEED), ("rail_exit_angle_of_attack", _abi.SUM_RAIL_EXIT_AOA),
-            ("rail_exit_sideslip", _abi.SUM_RAIL_EXIT_SIDESLIP), ("first_apogee_altitude", _abi.SUM_FIRST_APOGEE_ALT))}
-        impact = summ[[_abi.SUM_IMPACT_X, _abi.SUM_IMPACT_Y, _abi.SUM_IMPACT_Z]].T.tolist()
-        steps = summ[_abi.SUM_STEPS].astype(np.int64).tolist()
-        reason = [_END[k] for k in (status & 0xFF).tolist()]
-        chute = ((status & _abi.ST_CHUTE) != 0).tolist()
-        keys = list(cols)
-        results = []
-        for i, (params, *vals) in enumerate(zip(parameter_samples, *[cols[k] for k in keys])):
-            r = dict(zip(keys, vals))
-            r["impact_position"] = impact[i]
-            r["n_steps"] = steps[i]
-            r["termination"] = reason[i]
-            r["parachute_deployed"] = chute[i]
-            r["simulation_id"] = i
-            r["parameters"] = params
-            results.append(r)
+    def _sample_table(self, summ, status, parameter_samples, traj, lo):
+        """Columns of the run as a results.SampleTable (per-sample dicts are built on access)."""
+        trajectories = {}
         if traj is not None:
             ids, tr, tlen = traj
             tr, tlen = tr.cpu().numpy(), tlen.cpu().numpy()
             for m, i in enumerate(ids):
                 k = int(tlen[m])
                 rec = tr[m, :k]
-                results[lo + i]["trajectory"] = {           # monte_carlo.py:298-302
+                trajectories[lo + i] = {           # monte_carlo.py:298-302
                     "time": rec[:, 0] - summ[_abi.SUM_RAIL_EXIT_TIME, lo + i],
                     "altitude": rec[:, 3].copy(),
                     "position": rec[:, 1:4].copy(),
                 }
-        return results
+        return results_mod.SampleTable(summ, status, parameter_samples, trajectories)
+
+    def _result_dicts(self, summ, status, parameter_samples, traj, lo):
+        """The eager list of per-sample dicts (what round 2 returned; kept as the cross-check of LazyResults)."""
+        table = self._sample_table(summ, status, parameter_samples, traj, lo)
+        return [table.record(i) for i in range(table.n)]
 
     def run_monte_carlo(self, initial_conditions, n_samples=1000, n_processes=None, optimized=False):
-        """monte_carlo.py:52-90 (and :92-154 when optimized=True: seed-42 stream + 'performance')."""
+        """monte_carlo.py:52-90 (and :92-154 when optimized=True: seed-42 stream + 'performance').
+
+        Same inputs (bit for bit), same analysis dict.  `analysis['results']` / `['outliers']` are lazy sequences
+        (results.LazyResults): `len`, indexing, slicing, iteration and `+` behave like the reference's lists and
+        yield the same per-sample dicts, built on access; the outlier filter and the statistics run on the summary
+        columns.  `self.precision` picks the kernel build: "f64" (default) is the reference-order gate kernel -
+        100 % of the reference's outcomes at 0.56 M trajectories/s; "f64_fast" keeps 99.7-99.9 % of them (DESIGN.md
+        section 5) at 4-5 M trajectories/s and is what the 10^5 - 10^7-sample runs should use."""
         if self.verbose:
             print(f"Running Monte Carlo analysis with {n_samples} samples...")
         t0 = time.time()
-        if optimized:   # one sequential RandomState(42) stream (monte_carlo.py:181-201): a list by construction
-            params = batch_params = self._generate_parameter_samples_vectorized(n_samples)
-        else:           # per-sample RandomState(i) streams: keep the array form for the batch construction
-            batch_params = flatten.generate_parameter_arrays(self.uncertainty_params, n_samples)
-            params = flatten._arrays_to_params(batch_params)
-        summ, status, traj, lo = self.run_batch_arrays(initial_conditions, batch_params)
-        results = self._result_dicts(summ, status, params, traj, lo)
+        if optimized:   # one sequential RandomState(42) stream (monte_carlo.py:181-201)
+            params = flatten.generate_parameter_arrays(self.uncertainty_params, n_samples, stream="seed_42")
+        else:           # per-sample RandomState(i) streams
+            params = flatten.generate_parameter_arrays(self.uncertainty_params, n_samples)
+        summ, status, traj, lo = self.run_batch_arrays(initial_conditions, params)
+        table = self._sample_table(summ, status, params, traj, lo)
         if self.verbose:
-            print(f"Completed {len(results)} out of {n_samples} simulations")
-        out = self._analyze_results(results)
+            print(f"Completed {table.n} out of {n_samples} simulations")
+        out = results_mod.analyze_table(table, verbose=self.verbose)
         if optimized:
             el = time.time() - t0
             _, ws = dist.world()
-            out["performance"] = {"total_time": el, "simulations_per_second": len(results) / el,
+            out["performance"] = {"total_time": el, "simulations_per_second": table.n / el,
                                   "cores_used": self.n_cores, "gpus_used": ws}
         return out
 
@@ -178,14 +196,27 @@ class MonteCarloAnalyzer:
         prec = _abi.PRECISIONS[precision]
         torch.cuda.synchronize(eng.device)
         t0 = time.time()
-        db = sampling.synthetic_dispersions(max(hi - lo, 1), self.rocket, self.motor, self.wind_model,
-                                            initial_conditions, eng.device, precision=prec, seed=seed + rank,
-                                            uncertainty=self.uncertainty_params,
-                                            base_altitude_profile=self.base_altitude_profile,
-                                            base_wind_profile=self.base_wind_profile, planar=planar, engine=eng)
-        torch.cuda.synchronize(eng.device)
-        t1 = time.time()
-        summ, status = eng.run(db)
+        # This rank's samples in sub-batches of CHUNK (the draws of sub-batch j come from seed + rank and j alone, so a
+        # run is reproducible for a given n_samples, world size and seed), every one handed to erpl_mc_submit_batch
+        # as soon as it is drawn: generation, up to `depth` integrations and their tails overlap on the GPU.
+        m = max(hi - lo, 1)
+        gen_s = 0.0
+        parts, inflight = [], []
+        for j, a in enumerate(range(0, m, self.CHUNK)):
+            tg = time.time()
+            db = sampling.synthetic_dispersions(min(self.CHUNK, m - a), self.rocket, self.motor, self.wind_model,
+                                                initial_conditions, eng.device, precision=prec,
+                                                seed=seed + rank + 1000003 * j, uncertainty=self.uncertainty_params,
+                                                base_altitude_profile=self.base_altitude_profile,
+                                                base_wind_profile=self.base_wind_profile, planar=planar, engine=eng)
+            gen_s += time.time() - tg
+            parts.append(eng.submit(db))
+            inflight.append(db)    # inputs outlive their batches: all of them are checked below before anything is freed
+        eng.wait()
+        eng.check()                # host-blocking; raises if a lane hand-over timed out
+        del inflight
+        summ = parts[0][0] if len(parts) == 1 else torch.cat([p[0] for p in parts], dim=1)
+        status = parts[0][1] if len(parts) == 1 else torch.cat([p[1] for p in parts])
         summ, status = summ[:, : hi - lo], status[: hi - lo]
         summ, status = dist.all_gather_summaries(summ, status, n_samples)
         torch.cuda.synchronize(eng.device)
@@ -195,8 +226,8 @@ class MonteCarloAnalyzer:
         t3 = time.time()
         out["summary"], out["status"] = summ, status
         out["performance"] = {"total_time": t3 - t0, "simulations_per_second": n_samples / (t3 - t0), "gpus_used": ws,
-                              "precision": precision, "generate_s": t1 - t0, "integrate_and_gather_s": t2 - t1,
-                              "statistics_s": t3 - t2}
+                              "precision": precision, "generate_s": gen_s, "integrate_and_gather_s": t2 - t0 - gen_s,
+                              "statistics_s": t3 - t2, "sub_batches": len(parts), "in_flight": eng.get_overlap()}
         return out
 
     def run_optimized_monte_carlo(self, initial_conditions, n_samples=1000, chunk_size=None):

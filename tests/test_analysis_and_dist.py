@@ -222,3 +222,79 @@ def test_two_rank_gloo_shard_and_gather(n):
     for rank, calls, summ, status in outs:
         assert np.array_equal(summ, ref_s, equal_nan=True), rank
         assert np.array_equal(status, ref_t), rank
+
+
+def _table_of(n, seed=5):
+    """A SampleTable with healthy, outlier and non-finite rows, real parameter arrays and one trajectory."""
+    from erpl_monte_carlo_sim_amd import results
+    rng = np.random.RandomState(seed)
+    summ = rng.normal(0, 1, (16, n))
+    summ[_abi.SUM_APOGEE_ALT] = rng.normal(25000, 20000, n)
+    summ[_abi.SUM_RANGE] = np.abs(rng.normal(50000, 90000, n))
+    summ[_abi.SUM_FLIGHT_TIME] = rng.normal(300, 150, n)
+    summ[_abi.SUM_APOGEE_ALT, :7] = [np.nan, np.inf, 50.0, 100.0, 80000.0, 88073.4, -np.inf]
+    summ[_abi.SUM_RANGE, 7:10] = [np.nan, 200000.0, 200000.1]
+    summ[_abi.SUM_STEPS] = rng.randint(100, 60000, n)
+    status = (rng.randint(0, 5, n) | (rng.randint(0, 2, n) << 9)).astype(np.int32)
+    params = flatten.generate_parameter_arrays(H.UNCERTAINTY, n)
+    traj = {11: {"time": np.arange(3.0), "altitude": np.arange(3.0), "position": np.zeros((3, 3))}}
+    return results.SampleTable(summ, status, params, traj)
+
+
+def test_lazy_results_equal_the_eager_list():
+    """`analysis['results']` / `['outliers']` are lazy sequences; they must yield the very dicts the
+    eager construction gives (same keys in the same order, same values and types), and the column-wise analysis
+    must equal analysis.analyze (itself pinned to the reference's numbers above) on that eager list."""
+    from erpl_monte_carlo_sim_amd import results
+    n = 1000
+    table = _table_of(n)
+    eager = [table.record(i) for i in range(n)]
+    ref = analysis.analyze([dict(r) for r in eager])
+    got = results.analyze_table(table)
+    for k in ("n_samples", "n_failed", "n_outliers", "apogee_altitude", "range", "flight_time", "parameter_ranges_observed"):
+        assert got[k] == ref[k], k
+    assert len(got["results"]) == ref["n_samples"] and len(got["outliers"]) == ref["n_outliers"]
+    assert got["results"] == ref["results"] and got["outliers"] == ref["outliers"]          # record by record
+    assert [r["simulation_id"] for r in got["outliers"]] == [r["simulation_id"] for r in ref["outliers"]]
+    assert got["outliers"][0]["outlier_reasons"] == ref["outliers"][0]["outlier_reasons"]
+    # list behaviour the reference's consumers rely on: indexing, negative indices, slices, iteration, `+`
+    lz = got["results"]
+    assert list(lz[3].keys()) == list(ref["results"][3].keys())
+    assert lz[-1]["simulation_id"] == ref["results"][-1]["simulation_id"]
+    assert [r["simulation_id"] for r in lz[5:9]] == [r["simulation_id"] for r in ref["results"][5:9]]
+    both = got["results"] + got["outliers"]
+    assert isinstance(both, list) and len(both) == n
+    assert type(lz[0]["apogee_altitude"]) is float and type(lz[0]["n_steps"]) is int
+    assert isinstance(lz[0]["parameters"]["initial_velocity_offset"], np.ndarray)
+    withtraj = [r for r in both if "trajectory" in r]
+    assert len(withtraj) == 1 and withtraj[0]["simulation_id"] == 11
+    assert np.array_equal(lz.column("apogee_altitude"), [r["apogee_altitude"] for r in ref["results"]])
+    with pytest.raises(ValueError, match="No physically reasonable"):
+        bad = _table_of(16)
+        bad.summary[_abi.SUM_APOGEE_ALT] = 9e4
+        results.analyze_table(bad)
+
+
+def test_lazy_analysis_equals_the_reference_statistics():
+    """analyze_table on the inputs of tests/golden/stats.json (the reference's own _analyze_results output; the
+    failed sample of that fixture has no counterpart on the GPU path and is left out on both sides)."""
+    from erpl_monte_carlo_sim_amd import results
+    g = H.load_json("stats.json")
+    inp = g["inputs"]
+    keep = [i for i in range(len(inp["apogee_altitude"])) if i != inp["none_index"]]
+    summ = np.zeros((16, len(keep)))
+    summ[_abi.SUM_APOGEE_ALT] = np.array(inp["apogee_altitude"], dtype=np.float64)[keep]
+    summ[_abi.SUM_RANGE] = np.array(inp["range"], dtype=np.float64)[keep]
+    summ[_abi.SUM_FLIGHT_TIME] = np.array(inp["flight_time"], dtype=np.float64)[keep]
+    P = flatten.generate_parameter_arrays(H.UNCERTAINTY, len(inp["apogee_altitude"]))
+    P = {k: v[keep] for k, v in P.items()}
+    out = results.analyze_table(results.SampleTable(summ, np.zeros(len(keep), dtype=np.int32), P))
+    assert out["n_samples"] == g["n_samples"] and out["n_outliers"] == g["n_outliers"]
+    for key in ("apogee_altitude", "range", "flight_time"):
+        for stat in ("mean", "std", "min", "max"):
+            assert out[key][stat] == pytest.approx(g[key][stat], rel=1e-14), (key, stat)
+        assert np.allclose(out[key]["percentiles"], g[key]["percentiles"], rtol=1e-14)
+    assert [r["outlier_reasons"] for r in out["outliers"]] == g["outlier_reasons"]
+    pr, gr = out["parameter_ranges_observed"], g["parameter_ranges_observed"]
+    for k in gr:
+        assert np.allclose(pr[k]["min"], gr[k]["min"], rtol=0, atol=0) and np.allclose(pr[k]["max"], gr[k]["max"], rtol=0, atol=0)

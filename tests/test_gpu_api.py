@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 import erpl_monte_carlo_sim_amd as E
-from erpl_monte_carlo_sim_amd import _abi
+import torch
+from erpl_monte_carlo_sim_amd import _abi, flatten
 
 import helpers as H
 
@@ -229,3 +230,48 @@ def test_library_first_then_torch_in_a_fresh_process():
             "eng = TrajectoryEngine(torch.device('cuda', 0)); eng.close(); print('ok')\n" % root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_chunked_pipeline_and_lazy_results_equal_one_batch():
+    """run_monte_carlo builds and submits its samples chunk by chunk (host preparation of chunk i+1 overlaps the
+    integration of chunk i) and returns lazy result sequences: same bits as one batch, same dicts as the eager
+    list (VERDICT r2 #2)."""
+    ref = None
+    for chunk in (131072, 300, 97):
+        mc = E.MonteCarloAnalyzer(E.Rocket(), E.LiquidMotor(), E.StandardAtmosphere(), E.WindModel(), verbose=False)
+        mc.base_altitude_profile, mc.base_wind_profile = H.CSV_ALT, H.CSV_WIND
+        mc.precision = "f64_fast"
+        mc.n_trajectories = 3
+        mc.CHUNK = chunk
+        params = flatten.generate_parameter_arrays(mc.uncertainty_params, 1000)
+        summ, status, traj, lo = mc.run_batch_arrays(dict(H.EXAMPLE_IC), params)
+        if ref is None:
+            ref = (summ, status)
+            eager = mc._result_dicts(summ, status, params, traj, lo)
+            out = mc.run_monte_carlo(dict(H.EXAMPLE_IC), n_samples=1000)
+            assert out["n_samples"] + out["n_outliers"] == 1000
+            both = {r["simulation_id"]: r for r in out["results"] + out["outliers"]}
+            from erpl_monte_carlo_sim_amd.results import _same_record
+            for i in (0, 1, 2, 3, 500, 999):      # incl. the samples that carry a trajectory
+                a, b = dict(both[i]), dict(eager[i])
+                a.pop("outlier_reasons", None)
+                assert _same_record(a, b), i
+            assert "trajectory" in both[0] and "trajectory" not in both[3]
+        else:
+            assert np.array_equal(summ, ref[0], equal_nan=True) and np.array_equal(status, ref[1]), chunk
+
+
+def test_run_monte_carlo_device_sub_batches():
+    """run_monte_carlo_device splits its samples into sub-batches handed to erpl_mc_submit_batch; the draws of a
+    sub-batch depend on (seed, rank, index of the sub-batch) only."""
+    mc = E.MonteCarloAnalyzer(E.Rocket(), E.LiquidMotor(), E.StandardAtmosphere(), E.WindModel(), verbose=False)
+    mc.CHUNK = 4096
+    a = mc.run_monte_carlo_device(dict(H.EXAMPLE_IC), 10000, seed=5)
+    b = mc.run_monte_carlo_device(dict(H.EXAMPLE_IC), 10000, seed=5)
+    assert a["performance"]["sub_batches"] == 3
+    assert torch.equal(a["status"], b["status"])
+    assert bool(((a["summary"] == b["summary"]) | (a["summary"].isnan() & b["summary"].isnan())).all())
+    assert a["n_samples"] + a["n_outliers"] == 10000 and sum(a["termination_counts"].values()) == 10000
+    mc.CHUNK = 131072
+    c = mc.run_monte_carlo_device(dict(H.EXAMPLE_IC), 4096, seed=5)      # = the first sub-batch of the runs above
+    assert torch.equal(c["status"], a["status"][:4096])
