@@ -202,16 +202,24 @@ class MonteCarloAnalyzer:
         m = max(hi - lo, 1)
         gen_s = 0.0
         parts, inflight = [], []
-        for j, a in enumerate(range(0, m, self.CHUNK)):
+        starts = list(range(0, m, self.CHUNK))
+        GROUP = 32   # sub-batches drawn before any of them is submitted (4 M samples, ~10 GB of wind tables at K = 100):
+        # a generation kernel enqueued behind a running flight launch waits for its waves to drain, so a group
+        # is drawn on an idle stream first (1.5 ms per sub-batch) and then handed over in one go
+        for g0 in range(0, len(starts), GROUP):
             tg = time.time()
-            db = sampling.synthetic_dispersions(min(self.CHUNK, m - a), self.rocket, self.motor, self.wind_model,
-                                                initial_conditions, eng.device, precision=prec,
-                                                seed=seed + rank + 1000003 * j, uncertainty=self.uncertainty_params,
-                                                base_altitude_profile=self.base_altitude_profile,
-                                                base_wind_profile=self.base_wind_profile, planar=planar, engine=eng)
+            group = []
+            for j in range(g0, min(g0 + GROUP, len(starts))):
+                a = starts[j]
+                group.append(sampling.synthetic_dispersions(
+                    min(self.CHUNK, m - a), self.rocket, self.motor, self.wind_model, initial_conditions, eng.device,
+                    precision=prec, seed=seed + rank + 1000003 * j, uncertainty=self.uncertainty_params,
+                    base_altitude_profile=self.base_altitude_profile, base_wind_profile=self.base_wind_profile,
+                    planar=planar, engine=eng))
             gen_s += time.time() - tg
-            parts.append(eng.submit(db))
-            inflight.append(db)    # inputs outlive their batches: all of them are checked below before anything is freed
+            for db in group:
+                parts.append(eng.submit(db))
+                inflight.append(db)    # inputs outlive their batches: all of them are checked below before anything is freed
         eng.wait()
         eng.check()                # host-blocking; raises if a lane hand-over timed out
         del inflight

@@ -49,8 +49,9 @@ for w in ("set_p_apogee", "set_p_apogee_gate", "set_p_full", "csv_chute", "set_s
         d = json.loads(open(p).read().strip().splitlines()[-1])
         extra[w] = {k: d[k] for k in keys if k in d}
         extra[w]["workload"] = d["config"]["workload"]
-        if "f64_fast" in d:
-            extra[w]["f64_fast"] = {k: d["f64_fast"][k] for k in keys if k in d["f64_fast"]}
+        for leg in ("f64_fast", "f32"):      # the secondary leg of the run, whichever it is
+            if leg in d:
+                extra[w][leg] = {k: d[leg][k] for k in keys if k in d[leg]}
 json.dump(extra, open(os.path.join(prof, f"{pre}_bench_other_workloads.json"), "w"), indent=1)
 
 # kernel stats (names truncated: torch's are hundreds of characters long)
@@ -68,7 +69,7 @@ for sub, out in (("stats", "bench_kernel_stats"), ("stats_gate", "bench_f64_gate
 # HBM traffic per launch, per kernel build (the bench command runs the f32 leg, then the f64_fast leg)
 fe, n = pmc("pmc_fetch")
 wr, _ = pmc("pmc_write")
-traffic = {"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python3 bench.py --steps 6 --warmup 3 --cpu-seconds 0 --no-parity",
+traffic = {"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python3 bench.py --steps 6 --warmup 3 --cpu-seconds 0 --no-parity --no-cfg5 --no-api",
            "workload": line["config"]["workload"], "passes_averaged": n, "gfx950_fetch_correction": 2.0,
            "note": "FETCH_SIZE on gfx950 reads 1/2 of a wide coalesced stream (MI355X_MICROARCH.md HBM section), so the read side is doubled; our loads are 4- and 8-byte-per-lane, for which the guide calls the counter uncalibrated: the corrected figure is an upper bound, the raw one a lower bound. The written bytes are 12 scattered 8-byte summary rows per sample, each costing a 32/64-byte write transaction, plus the rail kernel's resume records."}
 for name, suf in (("f32", "f32"), ("f64_fast", "f64f")):
@@ -80,7 +81,7 @@ for name, suf in (("f32", "f32"), ("f64_fast", "f64f")):
 json.dump(traffic, open(os.path.join(prof, f"{pre}_hbm_traffic.json"), "w"), indent=1)
 
 out = {}
-for sub, key in (("pmc_sq", "bench_command_f32_then_f64_fast"), ("pmc_sq_gate", "bench_command_f64_gate")):
+for sub, key in (("pmc_sq", "bench_command_f64_fast_then_f32"), ("pmc_sq_gate", "bench_command_f64_gate")):
     sq, n = pmc(sub)
     if sq:
         out[key] = {"passes_averaged": n, "counters_per_pass": sq}
