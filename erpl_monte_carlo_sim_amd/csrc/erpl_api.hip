@@ -346,7 +346,9 @@ void fill_common_args(const erpl_ctx* c, const erpl_batch* b, ErplKArgs& a) {
 // the launches behind the main one go to when the batch runs with lane adoption.
 int enqueue_batch(erpl_ctx* c, int lane, const erpl_batch* b, const erpl_out* o, hipStream_t st, int in_flight,
                   hipStream_t sweep, int64_t ticket) {
-  const int si = lane + (int)(c->lane_uses[lane] & 1u) * ERPL_MAX_OVERLAP;
+  // two workspaces per lane only where the lane's next batch may start beside the sweeps of its previous one (a sweep
+  // stream exists); erpl_mc_run_batch and lanes without lane adoption stay on their first set
+  const int si = lane + ((sweep && (c->lane_uses[lane] & 1u)) ? ERPL_MAX_OVERLAP : 0);
   ErplSlot& s = c->slot[si];
   int rc = slot_init(s);
   if (rc != ERPL_OK) return rc;
@@ -512,8 +514,12 @@ int erpl_mc_reserve(erpl_ctx* c, int64_t n) {
   // both workspaces of every lane in use now (erpl_mc_run_batch on lane 0 stays allocation-free, hence
   // graph-capturable, and no erpl_mc_submit_batch allocates in the middle of a run); lanes beyond the current depth
   // that have been used before grow too, fresh ones take the size on first use
+  // (the second workspace of a lane is only ever used with lane adoption on: without it, it is not allocated -
+  // a workspace costs 448 bytes per sample)
+  const bool may_adopt = c->adopt > 0 || (c->adopt < 0 && hw_queues_env() >= 2 * c->depth + 2);
   for (int i = 0; i < 2 * ERPL_MAX_OVERLAP; ++i) {
     if (i % ERPL_MAX_OVERLAP >= c->depth && !c->slot[i].d_queue) continue;
+    if (i >= ERPL_MAX_OVERLAP && !may_adopt && !c->slot[i].d_queue) continue;
     int rc = slot_init(c->slot[i]);
     if (rc == ERPL_OK) rc = slot_reserve(c->slot[i], c->reserve_n);
     if (rc != ERPL_OK) return rc;
