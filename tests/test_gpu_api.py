@@ -265,13 +265,13 @@ def test_run_monte_carlo_device_sub_batches():
     """run_monte_carlo_device splits its samples into sub-batches handed to erpl_mc_submit_batch; the draws of a
     sub-batch depend on (seed, rank, index of the sub-batch) only."""
     mc = E.MonteCarloAnalyzer(E.Rocket(), E.LiquidMotor(), E.StandardAtmosphere(), E.WindModel(), verbose=False)
-    mc.CHUNK = 4096
+    mc.DEVICE_CHUNK = 4096
     a = mc.run_monte_carlo_device(dict(H.EXAMPLE_IC), 10000, seed=5)
     b = mc.run_monte_carlo_device(dict(H.EXAMPLE_IC), 10000, seed=5)
     assert a["performance"]["sub_batches"] == 3
     assert torch.equal(a["status"], b["status"])
     assert bool(((a["summary"] == b["summary"]) | (a["summary"].isnan() & b["summary"].isnan())).all())
     assert a["n_samples"] + a["n_outliers"] == 10000 and sum(a["termination_counts"].values()) == 10000
-    mc.CHUNK = 131072
+    mc.DEVICE_CHUNK = 1 << 20
     c = mc.run_monte_carlo_device(dict(H.EXAMPLE_IC), 4096, seed=5)      # = the first sub-batch of the runs above
     assert torch.equal(c["status"], a["status"][:4096])
