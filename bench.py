@@ -227,8 +227,8 @@ def api_end_to_end(device, rocket, motor, atm, wm, n=1000000):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--samples-per-gpu", type=int, default=131072)
     ap.add_argument("--workload", default="set_s", choices=["set_s", "set_p_apogee", "set_p_full", "csv_chute"])
     ap.add_argument("--motor", default="liquid", choices=["liquid", "solid"])
