@@ -54,7 +54,9 @@ def main():
     suffix = {"f32": "f32", "f64_fast": "f64f", "f64": "f64"}
     out = {"command": "GPU_MAX_HW_QUEUES=24 rocprofv3 --kernel-trace -- python3 bench.py --gpus 1 --steps %d --warmup %d" % (K, W),
            "note": "union = total time during which at least one erpl_flight dispatch of the leg's timed passes is running; "
-                   "bench_ms_per_step is what the same (profiled) run printed", "legs": {}}
+                   "bench_ms_per_step is what the same (profiled) run printed; registers = (VGPR_Count, Accum_VGPR_Count) as "
+                   "rocprofv3 reports them for a wave64 kernel: half of the per-lane counts of profiles/r3_kernel_resource_usage.txt "
+                   "(128 = the 256-register two-wave build, 84 = the 168-register three-wave build)", "legs": {}}
     first_rail_after = {}
     def is_kernel(name, kind, build):
         """kind = "rail" | "flight"; the name may be mangled (erpl_rail_f64fE..., erpl_flight_f64fILb0...) or demangled."""
