@@ -46,13 +46,15 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")   # one hardware queue per batch in flight (include/erpl_mc.h), before HIP starts
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+# the package asks for one hardware queue per batch in flight (GPU_MAX_HW_QUEUES=24, include/erpl_mc.h) BEFORE HIP starts -
+# unless something has started HIP already (a profiler's preloaded library): then it leaves the default and warns,
+# and the library runs three deep (tools/*.sh export the variable for profiled runs)
+import erpl_monte_carlo_sim_amd  # noqa: E402,F401
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
-
-ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
 
 from erpl_monte_carlo_sim_amd import _abi, flatten, models, sampling  # noqa: E402
 from erpl_monte_carlo_sim_amd.engine import DeviceBatch, TrajectoryEngine  # noqa: E402
@@ -224,6 +226,50 @@ def api_end_to_end(device, rocket, motor, atm, wm, n=1000000):
     return out
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as FRESH child processes (RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, the same command line) BEFORE anything in this process
+    touches the GPU, pass their output through (rank 0 prints the ONE JSON line), and return non-zero if any rank
+    failed.  No re-exec: this process stays the parent and never initialises HIP (device_count() does not, on this image).
+    Replaces the pool start-up of monte_carlo.py:67-83."""
+    import socket
+    import subprocess
+    backend = os.environ.get("ERPL_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < n_ranks:
+        print(f"bench.py: {n_ranks} GPUs requested, {ndev} visible (RCCL needs one GPU per rank)", file=sys.stderr, flush=True)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), LOCAL_RANK=str(r),
+                   WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, kill_at = 0, None
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if 0 < code < 256 else 1
+                for q in alive:      # a rank that died leaves the others waiting in a collective: end exactly those
+                    q.terminate()
+                kill_at = time.monotonic() + 15.0
+        if kill_at is not None and time.monotonic() > kill_at:
+            for q in alive:
+                q.kill()
+            kill_at = None
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,13 +295,19 @@ def main():
     ap.add_argument("--chunk", type=int, default=-1, help="steps per launch between compactions (-1 = library default)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` typed as is: this process becomes the launcher (it never touches the GPU) and the
+        # N ranks are fresh children, exactly what torch.distributed.run would start
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU "
+                         f"(python bench.py --gpus N starts them itself)")
     ndev = torch.cuda.device_count()
+    if world > 1 and os.environ.get("ERPL_BENCH_BACKEND", "nccl") == "nccl" and ndev < world:
+        raise SystemExit(f"{world} GPUs requested, {ndev} visible: RCCL needs one GPU per rank")
     dev_index = local_rank % max(ndev, 1)   # one rank per GPU on the driver's 8-GPU node
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)

@@ -6,6 +6,13 @@ import sys as _sys
 
 
 def _hip_already_started():
+    """True when the HIP runtime may already have read GPU_MAX_HW_QUEUES: torch.cuda is initialised, or a tool that
+    starts HIP before the program does is attached (rocprofv3 and friends preload their library, which initialises
+    the runtime - with --pmc certainly - before the first line of Python runs)."""
+    env = _os.environ
+    if any(k in env for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCPROF_OUTPUT_PATH")) or \
+            any(w in env.get("LD_PRELOAD", "") for w in ("rocprof", "roctracer", "rocprofiler")):
+        return True
     t = _sys.modules.get("torch")
     try:
         return bool(t is not None and t.cuda.is_initialized())
@@ -21,9 +28,10 @@ def _hip_already_started():
 if "GPU_MAX_HW_QUEUES" not in _os.environ:
     if _hip_already_started():
         import warnings as _warnings
-        _warnings.warn("HIP was initialised before erpl_monte_carlo_sim_amd was imported: GPU_MAX_HW_QUEUES stays at the "
-                       "runtime's default (4 hardware queues), so submitted batches overlap three deep instead of eight. "
-                       "Import this package (or export GPU_MAX_HW_QUEUES=24) before the first torch.cuda call.")
+        _warnings.warn("HIP was (or may have been: a profiler is attached) initialised before erpl_monte_carlo_sim_amd was "
+                       "imported: GPU_MAX_HW_QUEUES stays at the runtime's default (4 hardware queues), so submitted batches "
+                       "overlap three deep instead of eight.  Export GPU_MAX_HW_QUEUES=24 in the environment of the "
+                       "process (or import this package before the first torch.cuda call).")
     else:
         _os.environ["GPU_MAX_HW_QUEUES"] = "24"
 

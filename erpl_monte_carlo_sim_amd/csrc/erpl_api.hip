@@ -218,6 +218,7 @@ static int hw_queues_env() {
 // Slot 0 serves erpl_mc_run_batch (on the caller's stream); slots 0..depth-1 serve erpl_mc_submit_batch
 // round-robin, each on its own internal stream.  Whoever uses a slot first waits (on the device) for
 // the slot's previous batch and records `done` behind its own kernels.
+#define ERPL_TICKET_RING 256
 struct ErplSlot {
   void* res_r[2] = {nullptr, nullptr};      // resume-queue records (see erpl_tables.h)
   double* res_d[2] = {nullptr, nullptr};
@@ -229,7 +230,10 @@ struct ErplSlot {
   hipEvent_t main_done = nullptr;           // its main flight launch has (the sweep stream waits for this)
   bool used = false;                        // `done` has been recorded at least once
   int64_t ticket = 0;                       // last batch submitted through this slot
-  unsigned long long* h_counters = nullptr; // pinned host copy of d_counters[0..3] of the slot's latest batch
+  unsigned long long* own_counters = nullptr; // pinned: d_counters[0..3] of the slot's latest erpl_mc_run_batch
+  unsigned long long* h_counters = nullptr; // pinned host copy of d_counters[0..3] of the slot's latest batch: `own_counters`,
+                                            // or the ticket record of the batch (erpl_mc_submit_batch)
+  bool latest_is_run = false;               // the slot's latest batch came through erpl_mc_run_batch (no ticket record)
   int64_t last_n = 0, seq = 0;              // its size and its position in the order of all batches of the context
 };
 
@@ -252,6 +256,15 @@ struct erpl_ctx {
   unsigned lane_uses[ERPL_MAX_OVERLAP] = {};   // batches the lane has taken: parity picks the set
   int depth = 3;                  // slots erpl_mc_submit_batch cycles through (erpl_mc_create: 8 with enough hardware queues)
   int64_t submitted = 0;          // tickets handed out
+  // One record per ticket: its own completion event and its own pinned copy of the batch's counters, so
+  // that erpl_mc_check_batch(T) waits for T alone and reports T's own lost records however often T's workspace has
+  // been reused since.  A ring of the last ERPL_TICKET_RING tickets; a record that leaves the ring unreported is
+  // latched in `recycled_incomplete`.
+  hipEvent_t ring_done[ERPL_TICKET_RING] = {};
+  int64_t ring_ticket[ERPL_TICKET_RING] = {};
+  unsigned long long* ring_counters = nullptr;   // pinned [ERPL_TICKET_RING][4]
+  int64_t acked = 0;                // tickets <= acked have been reported by a blocking check of ALL batches
+  int64_t recycled_incomplete = 0;  // first incomplete ticket that left the ring before such a check saw it
   int last_slot = 0;              // slot of the most recent batch (erpl_mc_last_stats)
   int64_t reserve_n = 0;          // erpl_mc_reserve request, applied to a slot when it is first used
   int adopt_spin = 1 << 22;       // polls of an adopting lane for a claimed record's ready word (erpl_mc_set_adopt_spin)
@@ -299,8 +312,9 @@ int slot_init(ErplSlot& s) {
   HIP_TRY(hipMalloc((void**)&s.d_queue, 2 * (ERPL_MAX_PHASES + 2) * sizeof(unsigned long long)));
   HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&s.main_done, hipEventDisableTiming));
-  HIP_TRY(hipHostMalloc((void**)&s.h_counters, 4 * sizeof(unsigned long long), hipHostMallocDefault));
-  memset(s.h_counters, 0, 4 * sizeof(unsigned long long));
+  HIP_TRY(hipHostMalloc((void**)&s.own_counters, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+  memset(s.own_counters, 0, 4 * sizeof(unsigned long long));
+  s.h_counters = s.own_counters;
   return ERPL_OK;
 }
 
@@ -309,7 +323,7 @@ void slot_destroy(ErplSlot& s) {
   (void)hipFree(s.d_counters); (void)hipFree(s.d_queue);
   if (s.done) (void)hipEventDestroy(s.done);
   if (s.main_done) (void)hipEventDestroy(s.main_done);
-  if (s.h_counters) (void)hipHostFree(s.h_counters);
+  if (s.own_counters) (void)hipHostFree(s.own_counters);
   s = ErplSlot();
 }
 
@@ -345,7 +359,7 @@ void fill_common_args(const erpl_ctx* c, const erpl_batch* b, ErplKArgs& a) {
 // Rail + flight kernels of one batch through the lane's next set, on stream `st`; `sweep` (or NULL) = the stream
 // the launches behind the main one go to when the batch runs with lane adoption.
 int enqueue_batch(erpl_ctx* c, int lane, const erpl_batch* b, const erpl_out* o, hipStream_t st, int in_flight,
-                  hipStream_t sweep, int64_t ticket) {
+                  hipStream_t sweep, int64_t ticket, unsigned long long* ring_slot = nullptr, hipEvent_t ring_done = nullptr) {
   // two workspaces per lane only where the lane's next batch may start beside the sweeps of its previous one (a sweep
   // stream exists); erpl_mc_run_batch and lanes without lane adoption stay on their first set
   const int si = lane + ((sweep && (c->lane_uses[lane] & 1u)) ? ERPL_MAX_OVERLAP : 0);
@@ -433,9 +447,12 @@ int enqueue_batch(erpl_ctx* c, int lane, const erpl_batch* b, const erpl_out* o,
   if (c->profiling && lrc == 0) c->profiled_runs++;
   if (lrc != 0) return fail(ERPL_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
   hipStream_t last = tail ? tail : st;
+  s.h_counters = ring_slot ? ring_slot : s.own_counters;
   HIP_TRY(hipMemcpyAsync(s.h_counters, s.d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, last));
   HIP_TRY(hipEventRecord(s.done, last));
+  if (ring_done) HIP_TRY(hipEventRecord(ring_done, last));
   s.used = true;
+  s.latest_is_run = ticket <= 0;
   if (ticket > 0) s.ticket = ticket;   // (an erpl_mc_run_batch on this set leaves the ticket: its `done` is later and covers it)
   s.last_n = b->n;
   s.seq = ++c->batches;
@@ -490,6 +507,8 @@ int erpl_mc_destroy(erpl_ctx* c) {
     if (c->lane_in_ready[i]) (void)hipEventDestroy(c->lane_in_ready[i]);
   }
   for (int i = 0; i < 3 * ERPL_PROFILE_RING; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for (int i = 0; i < ERPL_TICKET_RING; ++i) if (c->ring_done[i]) (void)hipEventDestroy(c->ring_done[i]);
+  if (c->ring_counters) (void)hipHostFree(c->ring_counters);
   delete c;
   return ERPL_OK;
 }
@@ -599,39 +618,84 @@ int erpl_mc_submit_batch(erpl_ctx* c, const erpl_batch* b, const erpl_out* o, vo
   // inputs written on the caller's stream so far are visible to the batch
   HIP_TRY(hipEventRecord(c->lane_in_ready[lane], (hipStream_t)stream));
   HIP_TRY(hipStreamWaitEvent(c->lane_stream[lane], c->lane_in_ready[lane], 0));
-  rc = enqueue_batch(c, lane, b, o, c->lane_stream[lane], c->depth, may_adopt ? c->lane_sweep[lane] : nullptr, c->submitted + 1);
+  // the ticket's own record: completion event + pinned counters (recycled ERPL_TICKET_RING tickets later)
+  const int64_t t_new = c->submitted + 1;
+  const int ri = (int)(t_new % ERPL_TICKET_RING);
+  if (!c->ring_counters) {
+    HIP_TRY(hipHostMalloc((void**)&c->ring_counters, ERPL_TICKET_RING * 4 * sizeof(unsigned long long), hipHostMallocDefault));
+    memset(c->ring_counters, 0, ERPL_TICKET_RING * 4 * sizeof(unsigned long long));
+  }
+  if (!c->ring_done[ri]) HIP_TRY(hipEventCreateWithFlags(&c->ring_done[ri], hipEventDisableTiming));
+  if (c->ring_ticket[ri] > 0) {   // the record of ticket t_new - ERPL_TICKET_RING leaves the ring: keep what nobody has been told yet
+    HIP_TRY(hipEventSynchronize(c->ring_done[ri]));
+    if (c->ring_counters[4 * ri + 3] != 0ull && c->ring_ticket[ri] > c->acked && c->recycled_incomplete == 0)
+      c->recycled_incomplete = c->ring_ticket[ri];
+  }
+  for (int i = 0; i < 2 * ERPL_MAX_OVERLAP; ++i)   // (a set idle since that ticket must not read the record's next life)
+    if (c->slot[i].h_counters == &c->ring_counters[4 * ri]) c->slot[i].h_counters = c->slot[i].own_counters;
+  memset(&c->ring_counters[4 * ri], 0, 4 * sizeof(unsigned long long));
+  c->ring_ticket[ri] = 0;
+  rc = enqueue_batch(c, lane, b, o, c->lane_stream[lane], c->depth, may_adopt ? c->lane_sweep[lane] : nullptr, t_new,
+                     &c->ring_counters[4 * ri], c->ring_done[ri]);
   if (rc != ERPL_OK) return rc;
+  c->ring_ticket[ri] = t_new;
   ++c->submitted;
   if (ticket) *ticket = c->submitted;
   return ERPL_OK;
 }
 
+namespace {
+// the record of ticket t, or -1 once it has left the ring (then the batch has finished: recycling waited for it)
+int ring_index(const erpl_ctx* c, int64_t t) {
+  const int ri = (int)(t % ERPL_TICKET_RING);
+  return (t > 0 && c->ring_ticket[ri] == t) ? ri : -1;
+}
+int report_incomplete(int64_t t, unsigned long long lost) {
+  return fail(ERPL_ERR_INCOMPLETE, "lane hand-over timed out in batch %lld: %llu record(s) lost, their samples carry ERPL_ST_INCOMPLETE",
+              (long long)t, lost);
+}
+// Blocking check of EVERY batch handed to the context so far; a failure is reported once: tickets up to the last one
+// are acknowledged afterwards (erpl_mc_check_batch(T) keeps answering for T itself while T's record is in the ring).
+int check_all(erpl_ctx* c) {
+  const int rc = wait_all_host(c);
+  if (rc != ERPL_OK) return rc;
+  int64_t bad = c->recycled_incomplete;
+  unsigned long long lost = 0ull;
+  for (int i = 0; i < ERPL_TICKET_RING; ++i) {
+    const int64_t t = c->ring_ticket[i];
+    if (t > c->acked && c->ring_counters[4 * i + 3] != 0ull && (bad == 0 || t < bad)) { bad = t; lost = c->ring_counters[4 * i + 3]; }
+  }
+  c->acked = c->submitted;
+  c->recycled_incomplete = 0;
+  if (bad > 0) return report_incomplete(bad, lost);
+  for (int i = 0; i < 2 * ERPL_MAX_OVERLAP; ++i)   // erpl_mc_run_batch batches carry no ticket: the set's own copy
+    if (c->slot[i].used && c->slot[i].latest_is_run && c->slot[i].own_counters[3] != 0ull)
+      return report_incomplete(0, c->slot[i].own_counters[3]);
+  return ERPL_OK;
+}
+}  // namespace
+
 int erpl_mc_wait_batch(erpl_ctx* c, int64_t ticket, void* stream) {
   if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
   if (ticket > c->submitted) return fail(ERPL_ERR_INVALID, "ticket %lld has not been handed out", (long long)ticket);
   HIP_TRY(hipSetDevice(c->device));
-  // The set that ran the batch still carries its ticket unless the lane has reused it since - and a set is reused
-  // only behind its previous batch (enqueue_batch waits for `done`), so then the later ticket's event covers it.
-  // (erpl_mc_run_batch's batches carry ticket 0 and are ordered by the caller's own stream.)
-  bool exact = false;
-  for (int i = 0; i < 2 * ERPL_MAX_OVERLAP && ticket > 0; ++i)
-    if (c->slot[i].used && c->slot[i].ticket == ticket) {
-      HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, c->slot[i].done, 0));
-      exact = true;
-    }
-  if (!exact)
-    for (int i = 0; i < 2 * ERPL_MAX_OVERLAP; ++i) {
-      ErplSlot& s = c->slot[i];
-      if (!s.used || s.ticket <= 0) continue;
-      if (ticket < 0 || (s.ticket > ticket && (s.ticket - ticket) % c->depth == 0))
-        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, s.done, 0));
-    }
+  if (ticket > 0) {
+    // the ticket's own event (a ticket that has left the ring has finished: nothing to order behind)
+    const int ri = ring_index(c, ticket);
+    if (ri >= 0) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, c->ring_done[ri], 0));
+  } else if (ticket < 0) {
+    // every set's latest batch; a set is reused only behind its previous batch, so this covers all of them
+    // (erpl_mc_run_batch's batches are ordered by the caller's own stream)
+    for (int i = 0; i < 2 * ERPL_MAX_OVERLAP; ++i)
+      if (c->slot[i].used && !c->slot[i].latest_is_run) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, c->slot[i].done, 0));
+  }
   // the host does not block here, so only batches that have ALREADY finished can be reported (their counters sit in
-  // pinned memory behind `done`); erpl_mc_check_batch / erpl_mc_synchronize are the blocking checks
-  for (int i = 0; i < 2 * ERPL_MAX_OVERLAP; ++i) {
-    ErplSlot& s = c->slot[i];
-    if (s.used && s.h_counters[3] != 0ull && hipEventQuery(s.done) == hipSuccess)
-      return fail(ERPL_ERR_INCOMPLETE, "lane hand-over timed out in batch %lld: its results are incomplete", (long long)s.ticket);
+  // pinned memory behind their event); erpl_mc_check_batch / erpl_mc_synchronize are the blocking checks
+  if (c->recycled_incomplete > 0) return report_incomplete(c->recycled_incomplete, 0ull);
+  for (int i = 0; i < ERPL_TICKET_RING; ++i) {
+    const int64_t t = c->ring_ticket[i];
+    if (t > c->acked && c->ring_counters[4 * i + 3] != 0ull && hipEventQuery(c->ring_done[i]) == hipSuccess)
+      return report_incomplete(t, c->ring_counters[4 * i + 3]);
   }
   return ERPL_OK;
 }
@@ -640,29 +704,21 @@ int erpl_mc_check_batch(erpl_ctx* c, int64_t ticket) {
   if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
   if (ticket > c->submitted) return fail(ERPL_ERR_INVALID, "ticket %lld has not been handed out", (long long)ticket);
   HIP_TRY(hipSetDevice(c->device));
-  for (int i = 0; i < 2 * ERPL_MAX_OVERLAP; ++i) {
-    ErplSlot& s = c->slot[i];
-    if (!s.used) continue;
-    // (a set reused since then has waited for the batch in question on the device: its own `done` covers it)
-    const bool covers = ticket < 0 || s.ticket == ticket || (s.ticket > ticket && s.ticket > 0 && (s.ticket - ticket) % c->depth == 0);
-    if (!covers) continue;
-    HIP_TRY(hipEventSynchronize(s.done));
-    if (s.h_counters[3] != 0ull && (ticket < 0 || s.ticket == ticket))
-      return fail(ERPL_ERR_INCOMPLETE, "lane hand-over timed out in batch %lld: %llu record(s) lost, their samples carry ERPL_ST_INCOMPLETE",
-                  (long long)s.ticket, (unsigned long long)s.h_counters[3]);
+  if (ticket <= 0) return check_all(c);
+  const int ri = ring_index(c, ticket);
+  if (ri < 0) {   // older than the ring: finished long ago; what is left of it is the latch
+    if (c->recycled_incomplete > 0) return report_incomplete(c->recycled_incomplete, 0ull);
+    return ERPL_OK;
   }
+  HIP_TRY(hipEventSynchronize(c->ring_done[ri]));   // this batch alone: later batches keep running
+  if (c->ring_counters[4 * ri + 3] != 0ull) return report_incomplete(ticket, c->ring_counters[4 * ri + 3]);
   return ERPL_OK;
 }
 
 int erpl_mc_synchronize(erpl_ctx* c) {
   if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
   HIP_TRY(hipSetDevice(c->device));
-  const int rc = wait_all_host(c);
-  if (rc != ERPL_OK) return rc;
-  for (int i = 0; i < 2 * ERPL_MAX_OVERLAP; ++i)   // counters of every finished batch sit in pinned memory
-    if (c->slot[i].used && c->slot[i].h_counters[3] != 0ull)
-      return fail(ERPL_ERR_INCOMPLETE, "lane hand-over timed out in batch %lld: its results are incomplete", (long long)c->slot[i].ticket);
-  return ERPL_OK;
+  return check_all(c);
 }
 
 int erpl_mc_set_profiling(erpl_ctx* c, int enable) {

@@ -56,8 +56,15 @@ def run_local_shard(n_total, local_batch, runner, group=None):
     [S, m] tensor, status [m] tensor).  Returns NumPy (summary [S, n_total], status [n_total]), identical
     on every rank.  Host preparation per rank is proportional to n_total / world."""
     rank, ws = world()
+    err = None
     if local_batch is not None and local_batch.n > 0:
-        summ, stat = runner(local_batch)
+        try:
+            summ, stat = runner(local_batch)
+        except Exception as e:   # noqa: BLE001 - re-raised below, after the collective every other rank is waiting in
+            if ws == 1:
+                raise
+            err = e
+            summ, stat = failed_shard(local_batch.n, group)
     else:
         summ = stat = None
     if ws == 1:
@@ -69,7 +76,20 @@ def run_local_shard(n_total, local_batch, runner, group=None):
     elif torch.distributed.get_backend(group) != "nccl":   # gloo (CPU tests, single-GPU rehearsals) gathers host tensors
         summ, stat = summ.cpu(), stat.cpu()
     full_s, full_t = all_gather_summaries(summ, stat, n_total, group)
+    if err is not None:
+        raise err
     return full_s.cpu().numpy(), full_t.cpu().numpy()
+
+
+def failed_shard(m, group=None):
+    """What a rank whose integration raised contributes to the gather (it must still take part, or the
+    other ranks wait in the collective for ever): NaN summaries and status words that carry ERPL_ST_INCOMPLETE, which
+    every rank refuses to hand on (TrajectoryEngine.raise_if_incomplete); the failing rank re-raises its own error."""
+    from . import _abi
+    nccl = torch.distributed.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+    return (torch.full((_abi.SUMMARY_DIM, m), float("nan"), dtype=torch.float64, device=dev),
+            torch.full((m,), _abi.ST_INCOMPLETE, dtype=torch.int32, device=dev))
 
 
 def run_sharded(host_batch, runner, group=None):

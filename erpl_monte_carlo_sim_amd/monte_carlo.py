@@ -95,18 +95,30 @@ class MonteCarloAnalyzer:
             traj = (ids, tr, tlen)
             parts.append((summ, status))
         inflight = []    # (ticket, inputs): the inputs must outlive their batch (it runs on the library's own streams)
-        keep = 2 * eng.get_overlap() + 1
+        # look-ahead: `depth` batches run, one more is queued behind them while the host builds the next chunk.
+        # erpl_mc_check_batch(T) waits for T's own event (batches behind it keep running) and answers for T itself.
+        keep = eng.get_overlap() + 1
+        incomplete = None
+
+        def retire(ticket):
+            nonlocal incomplete
+            try:
+                eng.check(ticket)   # host-blocking for that batch alone; raises if one of its lane hand-overs timed out
+            except _abi.IncompleteBatch as e:
+                # not raised here: in a multi-rank run the other ranks are on their way to the all-gather, and the
+                # status words of the lost samples carry ERPL_ST_INCOMPLETE through it - run_batch_arrays raises on
+                # EVERY rank from the gathered status
+                incomplete = incomplete or e
         for a in range(lo + m, hi, self.CHUNK):
             b = min(hi, a + self.CHUNK)
             db = DeviceBatch.from_host(host_batch(a, b), eng.device, prec)
             parts.append(eng.submit(db))
             inflight.append((eng.last_ticket, db))
-            if len(inflight) > keep:
-                eng.check(inflight[0][0])   # host-blocking, and raises if a lane hand-over of that batch timed out
-                inflight.pop(0)
+            while len(inflight) > keep:
+                retire(inflight.pop(0)[0])
         if inflight:
             eng.wait()
-            eng.check()
+            retire(-1)
         if len(parts) == 1:
             return parts[0][0], parts[0][1], traj
         return torch.cat([p[0] for p in parts], dim=1), torch.cat([p[1] for p in parts]), traj
@@ -207,30 +219,51 @@ class MonteCarloAnalyzer:
         gen_s = 0.0
         parts, inflight = [], []
         starts = list(range(0, m, self.DEVICE_CHUNK))
-        GROUP = 32   # sub-batches drawn before any of them is submitted (4 M samples, ~10 GB of wind tables at K = 100):
-        # a generation kernel enqueued behind a running flight launch waits for its waves to drain, so a group
-        # is drawn on an idle stream first (1.5 ms per sub-batch) and then handed over in one go
-        for g0 in range(0, len(starts), GROUP):
-            tg = time.time()
-            group = []
-            for j in range(g0, min(g0 + GROUP, len(starts))):
-                a = starts[j]
-                group.append(sampling.synthetic_dispersions(
-                    min(self.DEVICE_CHUNK, m - a), self.rocket, self.motor, self.wind_model, initial_conditions, eng.device,
-                    precision=prec, seed=seed + rank + 1000003 * j, uncertainty=self.uncertainty_params,
-                    base_altitude_profile=self.base_altitude_profile, base_wind_profile=self.base_wind_profile,
-                    planar=planar, engine=eng))
-            gen_s += time.time() - tg
-            for db in group:
-                parts.append(eng.submit(db))
-                inflight.append(db)    # inputs outlive their batches: all of them are checked below before anything is freed
-        eng.wait()
-        eng.check()                # host-blocking; raises if a lane hand-over timed out
-        del inflight
-        summ = parts[0][0] if len(parts) == 1 else torch.cat([p[0] for p in parts], dim=1)
-        status = parts[0][1] if len(parts) == 1 else torch.cat([p[1] for p in parts])
-        summ, status = summ[:, : hi - lo], status[: hi - lo]
+        # Sub-batches drawn before any of them is submitted: a sample budget (4 M samples, ~10 GB of wind tables at
+        # K = 100), not a count.  A generation kernel enqueued behind a running flight launch waits for its waves to
+        # drain, so a group is drawn on an idle stream first (1.5 ms per sub-batch) and then handed over in one go;
+        # the next group is drawn while the tails of this one fly.  A sub-batch's inputs are released as soon as ITS
+        # ticket has been checked (erpl_mc_check_batch waits for that batch alone).
+        GROUP = max(1, (4 << 20) // self.DEVICE_CHUNK)
+        keep = 2 * eng.get_overlap() + GROUP
+        err = None
+        try:
+            for g0 in range(0, len(starts), GROUP):
+                tg = time.time()
+                group = []
+                for j in range(g0, min(g0 + GROUP, len(starts))):
+                    a = starts[j]
+                    group.append(sampling.synthetic_dispersions(
+                        min(self.DEVICE_CHUNK, m - a), self.rocket, self.motor, self.wind_model, initial_conditions, eng.device,
+                        precision=prec, seed=seed + rank + 1000003 * j, uncertainty=self.uncertainty_params,
+                        base_altitude_profile=self.base_altitude_profile, base_wind_profile=self.base_wind_profile,
+                        planar=planar, engine=eng))
+                gen_s += time.time() - tg
+                for db in group:
+                    parts.append(eng.submit(db))
+                    inflight.append((eng.last_ticket, db))    # inputs outlive their batch
+                while len(inflight) > keep:
+                    eng.check(inflight.pop(0)[0])
+            eng.wait()
+            eng.check()                # host-blocking; raises if a lane hand-over timed out
+            inflight.clear()
+            summ = parts[0][0] if len(parts) == 1 else torch.cat([p[0] for p in parts], dim=1)
+            status = parts[0][1] if len(parts) == 1 else torch.cat([p[1] for p in parts])
+            summ, status = summ[:, : hi - lo], status[: hi - lo]
+        except Exception as e:   # noqa: BLE001 - re-raised below
+            if ws == 1:
+                raise
+            # the other ranks are waiting in the all-gather: take part with a shard marked incomplete, then raise
+            err = e
+            torch.cuda.synchronize(eng.device)
+            summ, status = dist.failed_shard(hi - lo)
+            if summ.device != eng.device and torch.distributed.get_backend() == "nccl":
+                summ, status = summ.to(eng.device), status.to(eng.device)
         summ, status = dist.all_gather_summaries(summ, status, n_samples)
+        if err is not None:
+            raise err
+        if ws > 1:
+            TrajectoryEngine.raise_if_incomplete(status)   # another rank's shard failed: every rank refuses the result
         torch.cuda.synchronize(eng.device)
         t2 = time.time()
         out = analysis.device_statistics(summ, status)

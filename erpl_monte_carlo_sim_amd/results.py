@@ -71,22 +71,38 @@ class SampleTable:
 
 
 class LazyResults(Sequence):
-    """`ids` (ascending sample ids) of a SampleTable as a read-only sequence of result dicts."""
+    """`ids` (ascending sample ids) of a SampleTable as a sequence of result dicts built on access.
+
+    A record that has been handed out is kept: indexing the same sample again returns the SAME dict, so that
+    reference-style consumers which annotate records in place (`r['x'] = ...` while iterating) find their writes
+    again.  The sequence itself is fixed (no append / sort / del); `tolist()` gives the plain mutable
+    list the reference returns (monte_carlo.py:296-302) - the deviation is listed in INTEGRATION.md."""
 
     def __init__(self, table, ids, with_reasons=False):
         self.table, self.ids, self.with_reasons = table, np.asarray(ids, dtype=np.int64), with_reasons
+        self._made = {}
 
     def __len__(self):
         return int(self.ids.size)
 
+    def _record(self, i):
+        r = self._made.get(i)
+        if r is None:
+            r = self._made[i] = self.table.record(i, self.with_reasons)
+        return r
+
     def __getitem__(self, k):
         if isinstance(k, slice):
-            return [self.table.record(int(i), self.with_reasons) for i in self.ids[k]]
-        return self.table.record(int(self.ids[k]), self.with_reasons)
+            return [self._record(int(i)) for i in self.ids[k]]
+        return self._record(int(self.ids[k]))
 
     def __iter__(self):
         for i in self.ids:
-            yield self.table.record(int(i), self.with_reasons)
+            yield self._record(int(i))
+
+    def tolist(self):
+        """The eager list of dicts (what the reference returns): every record is materialised (and kept)."""
+        return [self._record(int(i)) for i in self.ids]
 
     def __add__(self, other):        # `results + outliers` as the reference's lists allow
         return list(self) + list(other)

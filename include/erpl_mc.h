@@ -215,13 +215,18 @@ int erpl_mc_set_overlap(erpl_ctx* ctx, int depth);
 int erpl_mc_get_overlap(erpl_ctx* ctx);
 int erpl_mc_submit_batch(erpl_ctx* ctx, const erpl_batch* batch, const erpl_out* out, void* hip_stream, int64_t* ticket);
 int erpl_mc_wait_batch(erpl_ctx* ctx, int64_t ticket, void* hip_stream);
-/* Host-blocking wait for everything this context has enqueued; ERPL_ERR_INCOMPLETE if a lane hand-over of any
- * batch still on record timed out. */
+/* Host-blocking wait for everything this context has enqueued, then ERPL_OK, or ERPL_ERR_INCOMPLETE naming the first
+ * batch a lane hand-over of which timed out.  Reported ONCE: the batches up to the last ticket are acknowledged by
+ * this call (and by erpl_mc_check_batch(ctx, -1)), later calls answer for later batches. */
 int erpl_mc_synchronize(erpl_ctx* ctx);
-/* Where results are consumed: host-blocking wait for batch `ticket` alone (< 0: every batch submitted so far),
- * then ERPL_OK, or ERPL_ERR_INCOMPLETE if one of its lane hand-overs timed out (its unfinished samples carry
- * ERPL_ST_INCOMPLETE).  erpl_mc_wait_batch itself never blocks the host and therefore cannot know; it does
- * report ERPL_ERR_INCOMPLETE for batches that had already finished that way when it is called. */
+/* Where results are consumed: host-blocking wait for batch `ticket` ALONE - its own completion event, batches
+ * submitted after it keep running - then ERPL_OK, or ERPL_ERR_INCOMPLETE if one of ITS lane hand-overs timed out
+ * (its unfinished samples carry ERPL_ST_INCOMPLETE).  Every ticket has its own record (event + pinned copy of
+ * the batch's counters), so the answer does not depend on how often the batch's workspace has been reused since;
+ * the records of the last 256 tickets are kept, an unreported failure that leaves the ring is latched and comes
+ * back from the next call that checks an older ticket or all of them.  ticket < 0: every batch submitted so far
+ * (= erpl_mc_synchronize).  erpl_mc_wait_batch itself never blocks the host and therefore cannot know; it does
+ * report ERPL_ERR_INCOMPLETE for unacknowledged batches that had already finished that way when it is called. */
 int erpl_mc_check_batch(erpl_ctx* ctx, int64_t ticket);
 
 /* Launch geometry knobs (tuning / tests): threads per workgroup (default 64), max workgroups of the

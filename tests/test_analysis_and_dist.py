@@ -298,3 +298,96 @@ def test_lazy_analysis_equals_the_reference_statistics():
     pr, gr = out["parameter_ranges_observed"], g["parameter_ranges_observed"]
     for k in gr:
         assert np.allclose(pr[k]["min"], gr[k]["min"], rtol=0, atol=0) and np.allclose(pr[k]["max"], gr[k]["max"], rtol=0, atol=0)
+
+
+def _bench_cmd(*extra):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return [sys.executable, os.path.join(root, "bench.py"), *extra], env, root
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus 8` as the driver types it: the launcher counts the devices BEFORE starting ranks and
+    says what is wrong (here: no GPU at all; on a one-GPU box: "8 GPUs requested, 1 visible"), rc != 0."""
+    import subprocess
+    cmd, env, root = _bench_cmd("--gpus", "8", "--steps", "1", "--warmup", "0")
+    env.pop("ERPL_BENCH_BACKEND", None)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=root, timeout=300)
+    assert r.returncode != 0 and "8 GPUs requested" in r.stderr and "visible" in r.stderr, (r.stdout[-500:], r.stderr[-1500:])
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="needs a box WITHOUT a GPU: the ranks must fail")
+def test_bench_launcher_returns_nonzero_when_a_rank_fails():
+    """The self-launch path (no torch.distributed.run around it): two child ranks are started; without a GPU both
+    fail, the launcher ends whatever is left and reports a non-zero exit code, and prints no JSON line."""
+    import subprocess
+    cmd, env, root = _bench_cmd("--gpus", "2", "--steps", "1", "--warmup", "0", "--samples-per-gpu", "64")
+    env["ERPL_BENCH_BACKEND"] = "gloo"     # (skips the one-GPU-per-rank check so that ranks are actually started)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=root, timeout=600)
+    assert r.returncode != 0, (r.stdout[-500:], r.stderr[-1500:])
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def _worker_failing(rank, world, port, q):
+    import torch.distributed as td
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+
+    def runner(shard):
+        if rank == 1:
+            raise RuntimeError("rank 1 lost its GPU")
+        return torch.zeros((16, shard.n), dtype=torch.float64), torch.ones((shard.n,), dtype=torch.int32)
+
+    class Shard:
+        n = 3
+    try:
+        summ, status = dist.run_local_shard(6, Shard(), runner)
+        # the healthy rank gets the gathered block back - with the failed rank's samples marked incomplete
+        from erpl_monte_carlo_sim_amd.engine import TrajectoryEngine
+        try:
+            TrajectoryEngine.raise_if_incomplete(status)
+            q.put((rank, "no error", None))
+        except _abi.IncompleteBatch as e:
+            q.put((rank, "incomplete", int(np.sum((status & _abi.ST_INCOMPLETE) != 0))))
+    except RuntimeError as e:
+        q.put((rank, "raised", str(e)))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_a_failing_rank_still_takes_part_in_the_gather():
+    """an exception inside one rank's integration must not leave the other ranks waiting in the all-gather.
+    The failing rank contributes a shard marked ERPL_ST_INCOMPLETE, re-raises its own error afterwards, and the healthy
+    rank refuses the gathered result (raise_if_incomplete) instead of hanging or handing on half a batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_failing, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = dict((o[0], o[1:]) for o in [q.get(timeout=120) for _ in procs])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert outs[1] == ("raised", "rank 1 lost its GPU")
+    assert outs[0] == ("incomplete", 3)
+
+
+def test_lazy_results_hand_out_the_same_record_again():
+    """in-place annotations of a record survive (the reference returns plain lists of dicts), and tolist()
+    is that plain list."""
+    from erpl_monte_carlo_sim_amd import results
+    got = results.analyze_table(_table_of(200))
+    lz = got["results"]
+    for r in lz:
+        r["my_note"] = r["simulation_id"] * 2
+    assert all(r["my_note"] == r["simulation_id"] * 2 for r in lz)
+    assert lz[5] is lz[5] and lz[2:4][1] is lz[3]
+    lst = lz.tolist()
+    assert isinstance(lst, list) and len(lst) == len(lz) and lst[7] is lz[7]
+    lst.sort(key=lambda r: -r["apogee_altitude"])      # list operations work on the list
+    lst.append({"simulation_id": -1})
+    assert len(lz) == len(lst) - 1

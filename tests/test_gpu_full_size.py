@@ -235,24 +235,35 @@ def test_bench_two_ranks_on_one_gpu(tmp_path, mode):
     before anything in them touches the GPU.  `strong`: --total-samples splits a fixed sample count over the ranks
     (BASELINE configs[3]'s 1 048 576 over 1 / 2 / 4 / 8 GPUs the moment a node exists)."""
     import json
-    port = _free_port()
     n_rank = 16384
     extra = ["--total-samples", str(2 * n_rank)] if mode == "strong" else ["--samples-per-gpu", str(n_rank)]
+    # typed exactly as the driver types the N = 1 run, with --gpus 2: bench.py starts its two ranks itself
+    # (fresh children, the launching process never touches the GPU) and relays rank 0's line
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
            "--cpu-seconds", "0", "--no-parity", "--no-cfg5", "--no-api"] + extra
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), LOCAL_RANK=str(r),
-                   WORLD_SIZE="2", ERPL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
-    outs = [p.communicate(timeout=900) for p in procs]
-    for p, (so, se) in zip(procs, outs):
-        assert p.returncode == 0, (so[-1000:], se[-3000:])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ERPL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    outs = [(r.stdout, r.stderr)]
     lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
-    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]   # rank 0 prints the ONE line
+    assert len(lines) == 1   # rank 0 prints the ONE line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["value"] > 0 and d["dtype"] == "f64_fast"
     assert d["scaling"] == mode and d["config"]["samples_per_gpu"] == n_rank
     assert d["cpu_baseline"] is None and "f32" in d and d["f32"]["value"] > 0
     # value = the samples of BOTH ranks per second of the slowest rank
     assert d["value"] == pytest.approx(2 * n_rank * 4 / (d["ms_per_step"] * 4e-3), rel=1e-6)
+
+
+def test_bench_gpus_8_on_a_one_gpu_box_fails_clearly():
+    """`python bench.py --gpus 8` typed as the driver types it, on a box with fewer GPUs: a clear message and rc != 0
+    from the launcher, which never initialises the GPU itself."""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("this box really has 8 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "ERPL_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True,
+                       text=True, cwd=ROOT, timeout=300)
+    assert r.returncode != 0 and f"8 GPUs requested, {torch.cuda.device_count()} visible" in r.stderr, r.stderr[-1500:]

@@ -573,6 +573,48 @@ def test_timed_out_hand_over_is_reported_where_results_are_consumed(engine):
         engine.set_overlap(3)
 
 
+def test_check_of_an_old_ticket_after_its_workspace_was_reused(engine):
+    """every ticket has its own record.  A batch that finished incomplete is still reported by
+    erpl_mc_check_batch(its ticket) after 2 x depth + 1 later batches have reused its workspace (the per-set counters
+    it used to be read from have been overwritten by then), a clean later ticket checks clean in between, and the
+    check of ALL batches reports the failure once and acknowledges it."""
+    engine.set_config(H.make_config("liquid"))
+    rocket, motor, wm = models.Rocket(), models.LiquidMotor(), models.WindModel()
+    db = sampling.synthetic_dispersions(20000, rocket, motor, wm, H.EXAMPLE_IC, engine.device, precision=_abi.PREC_F64_FAST,
+                                        seed=33, engine=engine)
+    try:
+        engine.set_chunk(0)
+        engine.set_overlap(3)
+        engine.set_adopt(24)
+        engine.synchronize()
+        engine.set_adopt_spin(-1)
+        s, t = engine.submit(db)
+        bad = engine.last_ticket
+        engine.wait(bad)
+        torch.cuda.current_stream().synchronize()
+        assert int(((t & _abi.ST_INCOMPLETE) != 0).sum()) > 0
+        engine.set_adopt_spin(1 << 22)
+        later = []
+        for _ in range(2 * 3 + 1):                       # every set of the three lanes is reused at least once
+            engine.submit(db)
+            later.append(engine.last_ticket)
+        for tk in later:
+            engine.check(tk)                             # their own records: clean
+        with pytest.raises(_abi.IncompleteBatch, match=f"batch {bad}:"):
+            engine.check(bad)                            # the old ticket still answers for itself
+        with pytest.raises(_abi.IncompleteBatch, match=f"batch {bad}:"):
+            engine.check()                               # all batches: reported once ...
+        engine.check()                                   # ... and acknowledged
+        engine.synchronize()
+        with pytest.raises(_abi.IncompleteBatch):
+            engine.check(bad)                            # (the ticket's own record keeps the fact)
+    finally:
+        engine.set_adopt_spin(1 << 22)
+        engine.set_adopt(-1)
+        engine.set_chunk(-1)
+        engine.set_overlap(3)
+
+
 def test_soak_every_overlapped_batch_equals_run_batch():
     """tools/soak_adopt.py as a (short) test: full-size batches eight deep with lane adoption and its sweep
     launches on, every batch compared bit for bit with erpl_mc_run_batch of the same inputs (round 2 ran 696
