@@ -223,7 +223,11 @@ struct ErplSlot {
   void* res_r[2] = {nullptr, nullptr};      // resume-queue records (see erpl_tables.h)
   double* res_d[2] = {nullptr, nullptr};
   int32_t* res_i[2] = {nullptr, nullptr};
-  unsigned long long* d_queue = nullptr;    // qcnt[ERPL_MAX_PHASES + 2] followed by qhead[...]
+  unsigned long long* d_queue = nullptr;    // qcnt[ERPL_MAX_PHASES + 2], qhead[...], then the hand-over queue's two cursor arrays
+  void* ext_r = nullptr;                    // hand-over queue records (fp64 throughput build -> reference-order kernel),
+  double* ext_d = nullptr;                  //   allocated with the first ERPL_PREC_F64_FAST batch of the set
+  int32_t* ext_i = nullptr;
+  int64_t ext_cap = 0;
   unsigned long long* d_counters = nullptr; // 16 words
   int64_t cap = 0;
   hipEvent_t done = nullptr;                // everything of the slot's latest batch has run
@@ -288,7 +292,23 @@ void slot_free_workspace(ErplSlot& s) {
     (void)hipFree(s.res_r[k]); (void)hipFree(s.res_d[k]); (void)hipFree(s.res_i[k]);
     s.res_r[k] = nullptr; s.res_d[k] = nullptr; s.res_i[k] = nullptr;
   }
+  (void)hipFree(s.ext_r); (void)hipFree(s.ext_d); (void)hipFree(s.ext_i);
+  s.ext_r = nullptr; s.ext_d = nullptr; s.ext_i = nullptr; s.ext_cap = 0;
   s.cap = 0;
+}
+
+// The hand-over queue of the set (one more record buffer), for batches of the fp64 throughput build.
+int slot_reserve_handoff(ErplSlot& s) {
+  if (s.ext_cap >= s.cap) return ERPL_OK;
+  if (s.used) HIP_TRY(hipEventSynchronize(s.done));
+  (void)hipFree(s.ext_r); (void)hipFree(s.ext_d); (void)hipFree(s.ext_i);
+  s.ext_r = nullptr; s.ext_d = nullptr; s.ext_i = nullptr; s.ext_cap = 0;
+  const size_t rows = (size_t)s.cap;
+  HIP_TRY(hipMalloc(&s.ext_r, rows * ERPL_RES_R * sizeof(double)));
+  HIP_TRY(hipMalloc((void**)&s.ext_d, rows * ERPL_RES_D * sizeof(double)));
+  HIP_TRY(hipMalloc((void**)&s.ext_i, rows * ERPL_RES_I * sizeof(int32_t)));
+  s.ext_cap = s.cap;
+  return ERPL_OK;
 }
 
 // Grows the slot's workspace to n samples.  The slot's previous batch may still be using the old one.
@@ -309,7 +329,7 @@ int slot_reserve(ErplSlot& s, int64_t n) {
 int slot_init(ErplSlot& s) {
   if (s.d_queue) return ERPL_OK;
   HIP_TRY(hipMalloc((void**)&s.d_counters, 16 * sizeof(unsigned long long)));
-  HIP_TRY(hipMalloc((void**)&s.d_queue, 2 * (ERPL_MAX_PHASES + 2) * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc((void**)&s.d_queue, (2 * (ERPL_MAX_PHASES + 2) + 2 * ERPL_EXT_Q) * sizeof(unsigned long long)));
   HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&s.main_done, hipEventDisableTiming));
   HIP_TRY(hipHostMalloc((void**)&s.own_counters, 4 * sizeof(unsigned long long), hipHostMallocDefault));
@@ -377,6 +397,13 @@ int enqueue_batch(erpl_ctx* c, int lane, const erpl_batch* b, const erpl_out* o,
   for (int k = 0; k < 2; ++k) { a.res_r[k] = s.res_r[k]; a.res_d[k] = s.res_d[k]; a.res_i[k] = s.res_i[k]; }
   a.res_cap = s.cap;
   a.qcnt = s.d_queue; a.qhead = s.d_queue + (ERPL_MAX_PHASES + 2);
+  if (b->precision == ERPL_PREC_F64_FAST) {
+    rc = slot_reserve_handoff(s);
+    if (rc != ERPL_OK) return rc;
+    a.ext_r = s.ext_r; a.ext_d = s.ext_d; a.ext_i = s.ext_i;
+  }
+  a.ext_q = s.d_queue + 2 * (ERPL_MAX_PHASES + 2);
+  a.ext_cnt = a.ext_q + 1;
   a.n_traj = o->n_traj; a.traj_stride = o->traj_stride; a.traj_cap = o->traj_cap;
   a.traj_ids = o->traj_ids; a.traj = o->traj; a.traj_len = o->traj_len;
   a.counters = s.d_counters;

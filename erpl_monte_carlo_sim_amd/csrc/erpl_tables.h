@@ -15,6 +15,7 @@
 #define ERPL_RES_D 5
 #define ERPL_RES_I 6
 #define ERPL_MAX_PHASES 2048
+#define ERPL_EXT_Q 4            // words per cursor array of the hand-over queue (phases 0..3 of the sweep launch)
 #define ERPL_COAST_TABLE 2048   // rail-iteration counts covered by the NaN fast-forward table
 
 // Scalar constants, uniform over the batch.  X-macro so the fp64 master copy can be converted to
@@ -96,6 +97,15 @@ struct ErplKArgs {
   int64_t res_cap;
   unsigned long long* qcnt;    // [ERPL_MAX_PHASES + 2] records available to phase p (phase 0: n)
   unsigned long long* qhead;   // [ERPL_MAX_PHASES + 2] pop cursor of phase p
+  // Hand-over queue (fp64 throughput build -> reference-order kernel, ERPL_HANDOFF in erpl_kernels.inc): records of
+  // the lanes that left the RK4 loop at an unphysical speed, same layout and capacity as one resume-queue buffer.
+  // The sweep launch of the reference-order kernel pops them as ITS phase 1: res_*[1] = ext_*, qcnt = ext_q
+  // (ext_cnt = &ext_q[1]), qhead = ext_q + ERPL_EXT_Q.  NULL / unused in the other builds.
+  void* ext_r;
+  double* ext_d;
+  int32_t* ext_i;
+  unsigned long long* ext_q;   // [2 * ERPL_EXT_Q] behind qhead in the same allocation (zeroed by the rail kernel)
+  unsigned long long* ext_cnt;
   int32_t phase;               // index of this flight launch
   int32_t chunk_steps;         // RK4 steps a lane may take per launch (<= 0: unlimited, one launch)
   int32_t waves_per_simd;      // fp32 flight-kernel build to launch: 2 (256 VGPRs) or 3 (168 VGPRs, spills)
@@ -131,6 +141,11 @@ int erpl_launch_f32(const ErplKArgs& a, const void* scalars, int block, int max_
                     void* tail_stream, void* main_done);
 int erpl_launch_f64f(const ErplKArgs& a, const void* scalars, int block, int max_blocks, int n_phases, void* stream, void** ev,
                     void* tail_stream, void* main_done);
+// The sweep of the fp64 throughput build's hand-over queue by the reference-order flight kernel (no rail launch): `a` is
+// the batch's argument block with the hand-over queue mapped as phase 1 (see ErplKArgs::ext_r).  Compiled for <= 256
+// registers (two waves per SIMD, spills to scratch: it makes a few steps per record) so that its workgroups start
+// beside the throughput build's waves instead of waiting for an empty SIMD.
+int erpl_launch_f64_sweep(const ErplKArgs& a, const void* scalars, int block, int max_blocks, void* stream);
 // known-answer evaluation of one device function per lane (erpl_mc_debug_eval); in / out are [rows][m]
 int erpl_launch_debug_f64(const ErplKArgs& a, const void* scalars, int what, int64_t m, const double* in, double* out, void* stream);
 int erpl_launch_debug_f32(const ErplKArgs& a, const void* scalars, int what, int64_t m, const double* in, double* out, void* stream);

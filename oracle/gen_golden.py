@@ -7,7 +7,7 @@ The fixtures are DATA (flattened inputs + expected outputs); no reference source
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python3 oracle/gen_golden.py [--jobs 8]
 
-What is captured:
+What is captured (G4, the sensitivity record, is oracle/gen_sensitivity.py -> sensitivity.json):
   kat.json            function-level known answers (atmosphere, gravity, mass props, aero
                       coefficients, np.interp edge cases, wind lookup, RHS `_rocket_dynamics`)
   params.json         dispersion stream `_generate_parameter_samples` (seed=i) and the seed-42

@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""G4 sensitivity record - TEST INFRASTRUCTURE, runs only in the build container.
+
+How much of the reference's outcome (its `apogee_altitude` = global argmax over all steps, simulator.py:488-490,
+and the way the flight ends, :216 / :238-264) survives a tiny change of the inputs or of the rounding?  This is the
+evidence the apogee-match thresholds of tests/ and bench.py rest on:
+
+  (a) the CPU oracle against itself on Set R (BASELINE cfg 2's recipe: samples i = 0..n-1 drawn exactly as
+      monte_carlo.py:156-179 / :225-288, CSV base wind) with every input scaled by (1 + eps * s), s = +-1 iid
+      ("iid") or with dry_mass alone scaled by (1 + eps) ("dry_mass"), eps = 1e-16 .. 1e-8;
+  (b) the oracle against the SAME C source compiled with -ffp-contract=fast -mfma (every a*b+c fused: the
+      rounding pattern of a GPU build with FMA contraction);
+  (c) the Python reference itself (imported from /root/reference, never copied) against itself on a few samples
+      with dry_mass scaled by (1 + eps), next to the oracle's answer for the same samples and eps - pins (a) to
+      the real reference.
+
+A sample "matches" when |apogee' - apogee| <= 1e-3 |apogee| (both NaN counts as equal) AND the flight ends for the
+same reason.  Output: tests/golden/sensitivity.json (rates, error quantiles and the ids of the samples that differ).
+
+    PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python3 oracle/gen_sensitivity.py [--n 4000] [--ref-samples 48] [--jobs 8]
+"""
+import argparse
+import contextlib
+import ctypes as C
+import io
+import json
+import os
+import subprocess
+import sys
+import time
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference/rocket_simulation"
+OUT = os.path.join(ROOT, "tests", "golden", "sensitivity.json")
+sys.dont_write_bytecode = True
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+
+from erpl_monte_carlo_sim_amd import _abi, flatten, models, sampling  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+IC = {"position": [0.0, 0.0, 10.0], "velocity": [0, 0, 0.0],
+      "attitude": [0.0, -np.pi / 2 + 0.02, 0.0], "angular_velocity": [0.0, 0.0, 0.0]}
+CSV_ALT = np.array([0.0, 5000.0, 10000.0, 15000.0, 20000.0, 25000.0])
+CSV_WIND = np.array([[2.0, 0, 0], [5, 1, 0], [8, 2, 0], [10, 2, 0], [12, 3, 0], [15, 3, 0]])
+EPS = [1e-16, 1e-15, 1e-14, 1e-13, 1e-12, 1e-11, 1e-10, 1e-9, 1e-8]
+
+
+def relerr(a, b):
+    same = (a == b) | (np.isnan(a) & np.isnan(b))
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+        e = np.abs(a - b) / np.abs(b)
+    return np.where(same, 0.0, np.where(np.isnan(e), np.inf, e))
+
+
+def compare(base, other):
+    (bs, bt), (os_, ot) = base, other
+    e = relerr(os_[_abi.SUM_APOGEE_ALT], bs[_abi.SUM_APOGEE_ALT])
+    same_end = (bt & 0xFF) == (ot & 0xFF)
+    ok = (e <= 1e-3) & same_end
+    fin = np.isfinite(e)
+    return {"match_rate": float(np.mean(ok)), "apogee_within_0p1pct": float(np.mean(e <= 1e-3)),
+            "same_end_reason": float(np.mean(same_end)), "bit_identical_apogee": float(np.mean(e == 0.0)),
+            "median_apogee_err": float(np.median(e[fin])) if fin.any() else None,
+            "p99_apogee_err": float(np.percentile(e[fin], 99)) if fin.any() else None,
+            "differing_ids": [int(i) for i in np.nonzero(~ok)[0]]}
+
+
+def set_r(n):
+    rocket, motor, wm = models.Rocket(), models.LiquidMotor(), models.WindModel()
+    pl = flatten.generate_parameter_samples(sampling.DEFAULT_UNCERTAINTY, n)
+    hb = flatten.dispersed_batch(rocket, motor, wm, IC, pl, CSV_ALT, CSV_WIND)
+    cfg = flatten.config_from_objects(rocket, motor, models.StandardAtmosphere())
+    return cfg, hb
+
+
+def perturbed(hb, eps, mode, seed=20251005):
+    """A copy of the batch with inputs scaled by (1 + eps * s)."""
+    out = flatten.HostBatch(hb.n, hb.k_wind)
+    out.ic, out.rocket, out.motor = hb.ic.copy(), hb.rocket.copy(), hb.motor.copy()
+    out.alt_grid, out.wind = hb.alt_grid.copy(), hb.wind.copy()
+    if mode == "dry_mass":
+        out.rocket[0] = out.rocket[0] * (1.0 + eps)
+    else:
+        rng = np.random.RandomState(seed)
+        for name in ("ic", "rocket", "motor", "wind"):
+            a = getattr(out, name)
+            s = rng.randint(0, 2, a.shape) * 2.0 - 1.0
+            setattr(out, name, a * (1.0 + eps * s))
+    return out
+
+
+def fma_oracle():
+    """The oracle's source compiled with FMA contraction (-ffp-contract=fast -mfma): same code, fused rounding."""
+    so = os.path.join(HERE, "liberpl_oracle_fma.so")
+    subprocess.run(["make", "-C", HERE, "-s", "fma"], check=True)
+    L = C.CDLL(so)
+    L.erpl_oracle_run_batch.argtypes = [C.POINTER(_abi.ErplConfig), C.POINTER(_abi.ErplBatch), C.POINTER(_abi.ErplOut), C.c_int]
+
+    def run(cfg, hb, threads):
+        b = orc.host_batch_struct(hb)
+        summary = np.zeros((_abi.SUMMARY_DIM, hb.n))
+        status = np.zeros(hb.n, dtype=np.int32)
+        o = _abi.ErplOut()
+        o.summary, o.status = summary.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p)
+        rc = L.erpl_oracle_run_batch(C.byref(cfg), C.byref(b), C.byref(o), threads)
+        assert rc == 0
+        return summary, status
+    return run
+
+
+# ---------------------------------------------------------------------------------------- the Python reference
+def _ref_job(spec):
+    i, eps = spec
+    sys.path.insert(0, REF)
+    import environment as ref_env
+    import monte_carlo as ref_mc
+    import motor as ref_motor
+    import rocket as ref_rocket
+    with contextlib.redirect_stdout(io.StringIO()):
+        rk = ref_rocket.Rocket()
+        rk.dry_mass = rk.dry_mass * (1.0 + eps)
+        an = ref_mc.MonteCarloAnalyzer(rk, ref_motor.LiquidMotor(), ref_env.StandardAtmosphere(), ref_env.WindModel())
+        an.base_altitude_profile, an.base_wind_profile = ref_env.WindModel().load_wind_profile_from_csv(
+            os.path.join(REF, "sample_wind.csv"))
+        params = an._generate_parameter_samples(i + 1)[i]
+        res = an._run_single_simulation(dict(IC), params, i)
+    return i, eps, float(res["apogee_altitude"]), float(res["flight_time"]), float(res["range"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=4000)
+    ap.add_argument("--ref-samples", type=int, default=48)
+    ap.add_argument("--jobs", type=int, default=8)
+    args = ap.parse_args()
+    t0 = time.time()
+    cfg, hb = set_r(args.n)
+    base = orc.run_batch(cfg, hb, threads=args.jobs)
+    out = {"set": f"Set R: samples 0..{args.n - 1}, reference dispersion streams (seed = i), LiquidMotor, CSV base wind (K = 6), "
+                  "full termination logic", "n": args.n,
+           "criterion": "|apogee' - apogee| <= 1e-3 |apogee| (NaN == NaN) and same end reason",
+           "oracle_perturbed_inputs": {"iid": {}, "dry_mass": {}}}
+    nan = (base[1] & _abi.ST_NAN) != 0
+    calm = (~nan) & (base[0][_abi.SUM_APOGEE_ALT] == base[0][_abi.SUM_FIRST_APOGEE_ALT])
+    out["reference_classes"] = {"apogee_before_first_descent": float(np.mean(calm)),
+                                "apogee_after_first_descent": float(np.mean((~nan) & ~calm)),
+                                "altitude_turned_nan": float(np.mean(nan))}
+    for mode in ("iid", "dry_mass"):
+        for eps in EPS:
+            r = compare(base, orc.run_batch(cfg, perturbed(hb, eps, mode), threads=args.jobs))
+            out["oracle_perturbed_inputs"][mode][f"{eps:g}"] = r
+            print(f"{mode:9s} eps {eps:g}: match {r['match_rate']:.5f} median err {r['median_apogee_err']:.3g} "
+                  f"p99 {r['p99_apogee_err']:.3g}  ({time.time() - t0:.0f} s)", flush=True)
+    r = compare(base, fma_oracle()(cfg, hb, args.jobs))
+    out["oracle_fma_contracted_build"] = {"flags": "-ffp-contract=fast -mfma (same source, same inputs)", **r}
+    print(f"fma build: match {r['match_rate']:.5f} bit-identical {r['bit_identical_apogee']:.3f} median err {r['median_apogee_err']:.3g}", flush=True)
+    # ---- (c) the Python reference against itself
+    if args.ref_samples > 0:
+        from multiprocessing import Pool
+        eps_ref = [0.0, 1e-12, 1e-10]
+        jobs = [(i, e) for i in range(args.ref_samples) for e in eps_ref]
+        with Pool(args.jobs) as pool:
+            rows = pool.map(_ref_job, jobs, chunksize=1)
+        table = {(i, e): (a, ft, rg) for i, e, a, ft, rg in rows}
+        ref = {"samples": args.ref_samples, "perturbation": "dry_mass * (1 + eps) on the reference's own Rocket object", "eps": {}}
+        sub = flatten.HostBatch(args.ref_samples, hb.k_wind)
+        sub.ic, sub.rocket, sub.motor = hb.ic[:, :args.ref_samples].copy(), hb.rocket[:, :args.ref_samples].copy(), hb.motor[:, :args.ref_samples].copy()
+        sub.alt_grid, sub.wind = hb.alt_grid.copy(), np.ascontiguousarray(hb.wind[:, :, :args.ref_samples])
+        ob = orc.run_batch(cfg, sub, threads=args.jobs)
+        a0 = np.array([table[(i, 0.0)][0] for i in range(args.ref_samples)])
+        f0 = np.array([table[(i, 0.0)][1] for i in range(args.ref_samples)])
+        ref["oracle_vs_reference_unperturbed"] = {
+            "max_apogee_err": float(np.max(relerr(ob[0][_abi.SUM_APOGEE_ALT], a0))),
+            "max_flight_time_err": float(np.max(relerr(ob[0][_abi.SUM_FLIGHT_TIME], f0)))}
+        for e in eps_ref[1:]:
+            a1 = np.array([table[(i, e)][0] for i in range(args.ref_samples)])
+            f1 = np.array([table[(i, e)][1] for i in range(args.ref_samples)])
+            er = relerr(a1, a0)
+            ok = (er <= 1e-3) & (relerr(f1, f0) <= 1e-9)      # same end <=> same number of steps
+            op = orc.run_batch(cfg, perturbed(sub, e, "dry_mass"), threads=args.jobs)
+            eo = relerr(op[0][_abi.SUM_APOGEE_ALT], ob[0][_abi.SUM_APOGEE_ALT])
+            fin = np.isfinite(er) & np.isfinite(eo)
+            ref["eps"][f"{e:g}"] = {"reference_self_match_rate": float(np.mean(ok)),
+                                    "reference_max_apogee_err": float(np.max(er[np.isfinite(er)])),
+                                    "oracle_self_match_rate": float(np.mean((eo <= 1e-3) & ((op[1] & 0xFF) == (ob[1] & 0xFF)))),
+                                    "oracle_max_apogee_err": float(np.max(eo[np.isfinite(eo)])),
+                                    "amplification_median": float(np.median(er[fin & (er > 0)] / e)) if (fin & (er > 0)).any() else None}
+            print(f"reference eps {e:g}: self-match {ref['eps'][f'{e:g}']['reference_self_match_rate']:.4f} "
+                  f"max err {ref['eps'][f'{e:g}']['reference_max_apogee_err']:.3g} (oracle {ref['eps'][f'{e:g}']['oracle_max_apogee_err']:.3g})", flush=True)
+        out["python_reference"] = ref
+    with open(OUT, "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("written", OUT, f"{time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()

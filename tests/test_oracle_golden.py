@@ -261,3 +261,64 @@ def test_extract_histories_against_reference(oracle):
             scale = np.maximum(np.abs(gd[r]), 1e-6 * max(1.0, np.nanmax(np.abs(gd[r][fin[r]])) if fin[r].any() else 1.0))
             err = np.abs(got[r] - gd[r])[fin[r]] / scale[fin[r]]
             assert err.size == 0 or err.max() < 5e-10, (e["key"], name, err.max())
+
+
+def test_g4_sensitivity_record():
+    """the committed sensitivity record - what the apogee-match thresholds of the GPU
+    tests rest on - is reproduced by the oracle here on its first 1000 samples: the same source with FMA contraction
+    (the rounding pattern of the GPU throughput build) keeps every outcome, relative input perturbations up to 1e-13
+    keep every outcome, and the rate decays with the perturbation as recorded.  The record's section (c) pins these
+    figures to the Python reference itself (same maximum apogee error at eps = 1e-12 / 1e-10 on 48 samples)."""
+    import ctypes as C
+    import os
+    import subprocess
+    from erpl_monte_carlo_sim_amd import sampling
+    from oracle import oracle as orc
+    G = H.load_json("sensitivity.json")
+    assert G["n"] >= 2000 and G["oracle_fma_contracted_build"]["match_rate"] == 1.0
+    for mode in ("iid", "dry_mass"):
+        for eps in ("1e-16", "1e-15", "1e-14", "1e-13"):
+            assert G["oracle_perturbed_inputs"][mode][eps]["match_rate"] == 1.0, (mode, eps)
+        assert G["oracle_perturbed_inputs"][mode]["1e-12"]["match_rate"] >= 0.999
+        assert G["oracle_perturbed_inputs"][mode]["1e-10"]["match_rate"] < 0.995      # the 0.1 % bar IS sensitive above 1e-11
+    ref = G["python_reference"]
+    assert ref["oracle_vs_reference_unperturbed"]["max_apogee_err"] < 1e-7
+    for eps in ("1e-12", "1e-10"):   # the reference's own sensitivity equals the oracle's on the same samples
+        r = ref["eps"][eps]
+        assert r["reference_max_apogee_err"] == pytest.approx(r["oracle_max_apogee_err"], rel=0.05)
+        assert r["reference_self_match_rate"] == r["oracle_self_match_rate"]
+    # ---- recompute a slice here
+    n = 1000
+    rocket, motor, wm = models.Rocket(), models.LiquidMotor(), models.WindModel()
+    pl = flatten.generate_parameter_samples(sampling.DEFAULT_UNCERTAINTY, n)
+    hb = flatten.dispersed_batch(rocket, motor, wm, H.EXAMPLE_IC, pl, H.CSV_ALT, H.CSV_WIND)
+    cfg = flatten.config_from_objects(rocket, motor, models.StandardAtmosphere())
+    bs, bt = orc.run_batch(cfg, hb, threads=0)
+
+    def rate(s2, t2):
+        a, b = s2[_abi.SUM_APOGEE_ALT], bs[_abi.SUM_APOGEE_ALT]
+        with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+            e = np.where((a == b) | (np.isnan(a) & np.isnan(b)), 0.0, np.abs(a - b) / np.abs(b))
+        e = np.where(np.isnan(e), np.inf, e)
+        ok = (e <= 1e-3) & ((t2 & 0xFF) == (bt & 0xFF))
+        return float(np.mean(ok)), set(int(i) for i in np.nonzero(~ok)[0])
+    # (b) FMA-contracted build of the same source
+    here = os.path.dirname(orc.SO)
+    subprocess.run(["make", "-C", here, "-s", "fma"], check=True)
+    L = C.CDLL(os.path.join(here, "liberpl_oracle_fma.so"))
+    L.erpl_oracle_run_batch.argtypes = [C.POINTER(_abi.ErplConfig), C.POINTER(_abi.ErplBatch), C.POINTER(_abi.ErplOut), C.c_int]
+    b = orc.host_batch_struct(hb)
+    s2, t2 = np.zeros((_abi.SUMMARY_DIM, n)), np.zeros(n, dtype=np.int32)
+    o = _abi.ErplOut()
+    o.summary, o.status = s2.ctypes.data_as(C.c_void_p), t2.ctypes.data_as(C.c_void_p)
+    assert L.erpl_oracle_run_batch(C.byref(cfg), C.byref(b), C.byref(o), 0) == 0
+    assert rate(s2, t2)[0] == 1.0
+    assert not np.array_equal(s2[_abi.SUM_APOGEE_ALT], bs[_abi.SUM_APOGEE_ALT], equal_nan=True)   # it IS a different rounding
+    # (a) dry mass scaled by (1 + eps): same ids differ as in the record
+    for eps in (1e-13, 1e-10):
+        hp = flatten.HostBatch(n, hb.k_wind)
+        hp.ic, hp.rocket, hp.motor, hp.alt_grid, hp.wind = hb.ic.copy(), hb.rocket.copy(), hb.motor.copy(), hb.alt_grid.copy(), hb.wind.copy()
+        hp.rocket[0] = hp.rocket[0] * (1.0 + eps)
+        r, bad = rate(*orc.run_batch(cfg, hp, threads=0))
+        want = set(i for i in G["oracle_perturbed_inputs"]["dry_mass"][f"{eps:g}"]["differing_ids"] if i < n)
+        assert bad == want, (eps, sorted(bad ^ want))
