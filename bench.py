@@ -13,8 +13,9 @@ own 131 072-sample shard; `--total-samples N` splits a fixed N over the ranks in
 configs[3]'s 1 048 576 at 1 / 2 / 4 / 8 GPUs).
 
 The headline leg is the fp64 throughput build (ERPL_PREC_F64_FAST): it is the build that meets north_star's
-"per-sample apogee within 0.1 %" (apogee_match_rate 0.998; the fp32 build, which configs[2] names, reproduces
-the reference's apogee_altitude on 17 % of these samples and is reported as the secondary `f32` leg).
+"per-sample apogee within 0.1 %" (apogee_match_rate 1.0 since round 4: samples that blow up - speed above 1e6 m/s -
+finish in the reference-order kernel; the fp32 build, which configs[2] names, reproduces the reference's
+apogee_altitude on 17 % of these samples and is reported as the secondary `f32` leg).
 
 Passes are handed to the library with erpl_mc_submit_batch: up to `--overlap` of them are in flight
 on the library's internal streams (a pass over a batch that just fills the GPU lasts as long as its
@@ -101,10 +102,17 @@ def match_report(ref_s, ref_t, got_s, got_t):
     e_ap = relerr(got_s[_abi.SUM_APOGEE_ALT], ref_s[_abi.SUM_APOGEE_ALT])
     e_fa = relerr(got_s[_abi.SUM_FIRST_APOGEE_ALT], ref_s[_abi.SUM_FIRST_APOGEE_ALT])
     same_end = (got_t & 0xFF) == (ref_t & 0xFF)
+    fin = np.isfinite(e_ap)
     out = {"n": int(ref_s.shape[1]),
            "apogee_match_rate_0p1pct": float(np.mean(e_ap <= 1e-3)),
            "first_apogee_match_rate_0p1pct": float(np.mean(e_fa <= 1e-3)),
-           "same_end_reason": float(np.mean(same_end)), "by_reference_class": {}}
+           "same_end_reason": float(np.mean(same_end)),
+           "same_step_count": float(np.mean(got_s[_abi.SUM_STEPS] == ref_s[_abi.SUM_STEPS])),
+           # how far from the 0.1 % bar the build is (a regression shows here long before it costs a match)
+           "apogee_err_median": float(np.median(e_ap[fin])) if fin.any() else None,
+           "apogee_err_p99": float(np.percentile(e_ap[fin], 99)) if fin.any() else None,
+           "apogee_err_max_finite": float(e_ap[fin].max()) if fin.any() else None,
+           "by_reference_class": {}}
     nan = (ref_t & _abi.ST_NAN) != 0
     calm = (~nan) & (ref_s[_abi.SUM_APOGEE_ALT] == ref_s[_abi.SUM_FIRST_APOGEE_ALT])
     for name, m in (("apogee_before_first_descent", calm), ("apogee_after_first_descent", (~nan) & ~calm),
@@ -221,8 +229,8 @@ def api_end_to_end(device, rocket, motor, atm, wm, n=1000000):
             shape = {"raised": str(e)[:60]}
         el = (t2 if "n_valid" in shape else time.perf_counter()) - t1
         out["run_monte_carlo_" + precision] = {"n_samples": m, "total_time": el, "simulations_per_second": m / el, **shape}
-    out["note"] = ("run_monte_carlo defaults to precision 'f64' (the reference-order gate kernel: 100 % of the reference's "
-                   "outcomes); 'f64_fast' is the build for 10^5 - 10^7 samples (99.7-99.9 %)")
+    out["note"] = ("run_monte_carlo defaults to precision 'f64' (the reference-order gate kernel); 'f64_fast' is the build for "
+                   "10^5 - 10^7 samples (the same outcomes on every sample of the parity sets, see `parity`)")
     return out
 
 
@@ -356,8 +364,10 @@ def main():
     eng.reserve(n)
     side = torch.cuda.Stream(device) if world > 1 else None
 
-    def timed_leg(precision):
+    def timed_leg(precision, steps=None, warmup=None):
         """W warm-up + K timed passes of one kernel build; returns the measurements of this rank."""
+        steps = args.steps if steps is None else steps
+        warmup = args.warmup if warmup is None else warmup
         prec = _abi.PRECISIONS[precision]
         db = as_precision(db64, prec)
         depth = leg_depth(precision)
@@ -415,7 +425,7 @@ def main():
                 wait_gather(k)
 
         eng.set_profiling(True)
-        for i in range(args.warmup):
+        for i in range(warmup):
             step(i)
         drain()
         torch.cuda.synchronize()
@@ -425,7 +435,7 @@ def main():
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
-        for i in range(args.steps):
+        for i in range(steps):
             step(i)
         drain()
         ev1.record()
@@ -440,7 +450,7 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo_rehearsal else device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        last = (args.steps - 1) % nbuf
+        last = (steps - 1) % nbuf
         summary, status = outs[last]
         if world > 1:  # every rank must hold every rank's summaries: rank-major rows, own block == own results
             g_s, g_t = gath[last]
@@ -448,14 +458,14 @@ def main():
             if not bool(((own == summary) | (own.isnan() & summary.isnan())).all()) or \
                     not torch.equal(g_t[rank * n:(rank + 1) * n].to(status.device), status):
                 raise SystemExit("all-gather result does not contain this rank's summaries")
-        rail_ms, flight_ms = eng.kernel_ms_history(args.steps)
+        rail_ms, flight_ms = eng.kernel_ms_history(steps)
         phys_steps, wave_iters = eng.last_stats()
         phys_total = phys_steps
         if world > 1:
             tot = torch.tensor([phys_steps], dtype=torch.float64, device="cpu" if gloo_rehearsal else device)
             dist.all_reduce(tot)
             phys_total = float(tot.item())
-        return {"precision": precision, "prec": prec, "db": db, "elapsed": elapsed, "gpu_ms": gpu_ms, "depth": depth,
+        return {"steps": steps, "precision": precision, "prec": prec, "db": db, "elapsed": elapsed, "gpu_ms": gpu_ms, "depth": depth,
                 "summary": summary, "status": status, "rail_ms": rail_ms, "flight_ms": flight_ms,
                 "phys_steps": phys_steps, "wave_iters": wave_iters, "phys_total": phys_total}
 
@@ -463,9 +473,9 @@ def main():
         """The value / roofline part of the JSON line for one leg (rank 0)."""
         precision = L["precision"]
         total_traj = n * world
-        value = total_traj * args.steps / L["elapsed"]
+        value = total_traj * L["steps"] / L["elapsed"]
         fl, rl = float(np.mean(L["flight_ms"])), float(np.mean(L["rail_ms"]))
-        per_launch_ms = L["gpu_ms"] / args.steps     # GPU time per launch over the timed region (HIP events)
+        per_launch_ms = L["gpu_ms"] / L["steps"]     # GPU time per launch over the timed region (HIP events)
         peak = PEAK_TFLOPS[precision]
         achieved_tf = L["phys_steps"] * FLOPS_PER_STEP / (per_launch_ms * 1e-3) / 1e12
         dispatch_tf = L["phys_steps"] * FLOPS_PER_STEP / (fl * 1e-3) / 1e12
@@ -483,8 +493,8 @@ def main():
         st = L["status"].cpu().numpy()
         steps_col = L["summary"][_abi.SUM_STEPS].cpu().numpy()
         return {
-            "value": value, "unit": "trajectories/s", "ms_per_step": L["elapsed"] / args.steps * 1e3, "dtype": precision,
-            "trajectory_steps_per_s": L["phys_total"] * args.steps / L["elapsed"],
+            "value": value, "unit": "trajectories/s", "ms_per_step": L["elapsed"] / L["steps"] * 1e3, "dtype": precision,
+            "trajectory_steps_per_s": L["phys_total"] * L["steps"] / L["elapsed"],
             "steps_per_trajectory": {"mean": float(steps_col.mean()), "max": float(steps_col.max()),
                                      "physics_mean": L["phys_steps"] / n},
             "lane_utilisation": L["phys_steps"] / (64.0 * L["wave_iters"]) if L["wave_iters"] else None,
@@ -544,20 +554,18 @@ def main():
     if rank == 0 and world > 1:
         out["cpu_baseline"] = None   # measured by the N = 1 run only (the host cores are shared by the ranks)
     if rank == 0 and world == 1 and not args.no_parity:
-        # the fp64 reference-order gate kernel on the SAME shard: the per-sample reference for every timed build
-        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        g0.record()
-        gs, gt = eng.run(as_precision(db64, _abi.PREC_F64), flags=flags)
-        g1.record()
-        torch.cuda.synchronize()
-        gate_ms = g0.elapsed_time(g1)
-        gate_steps, _ = eng.last_stats()
-        gate_tf = gate_steps * FLOPS_PER_STEP / (gate_ms * 1e-3) / 1e12
-        out["f64_gate"] = {"note": "the fp64 reference-order kernel (ERPL_PREC_F64), ONE pass over the same shard, alone on the GPU",
-                           "ms": gate_ms, "value": n / gate_ms * 1e3, "unit": "trajectories/s",
-                           "roofline": {"bound": "valu", "achieved": gate_tf, "peak": PEAK_TFLOPS["f64"], "unit": "TFLOP/s",
-                                        "frac": gate_tf / PEAK_TFLOPS["f64"], "kernel": "erpl_flight_f64",
-                                        "rk4_steps_per_launch": gate_steps}}
+        # the fp64 reference-order gate kernel on the SAME shard: the per-sample reference for every timed build, and a
+        # timed leg of its own on the same footing as the others (erpl_mc_submit_batch at the library depth; fewer
+        # passes: one lasts ten times longer)
+        gate_leg = main_leg if args.precision == "f64" else timed_leg("f64", steps=max(2, min(args.steps, 8)), warmup=min(args.warmup, 2))
+        gj = leg_json(gate_leg)
+        out["f64_gate"] = {"note": "the fp64 reference-order kernel (ERPL_PREC_F64), the API default of run_monte_carlo: "
+                                   f"{gate_leg['steps']} passes over the same shard through erpl_mc_submit_batch, like the other legs",
+                           "value": gj["value"], "unit": gj["unit"], "ms_per_step": gj["ms_per_step"], "steps": gate_leg["steps"],
+                           "lane_utilisation": gj["lane_utilisation"], "kernel_ms": gj["kernel_ms"],
+                           "roofline": {k: gj["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel",
+                                                                       "rk4_steps_per_launch", "launch_duration_ms")}}
+        gs, gt = gate_leg["summary"], gate_leg["status"]
         gs, gt = gs.cpu().numpy(), gt.cpu().numpy()
         rep = match_report(gs, gt, main_leg["summary"].cpu().numpy(), main_leg["status"].cpu().numpy())
         out["apogee_match_rate"] = rep["apogee_match_rate_0p1pct"]
@@ -599,6 +607,8 @@ def main():
                         continue
                     got_s, got_t = L["summary"][:, :m].cpu().numpy(), L["status"][:m].cpu().numpy()
                     dst["parity"]["timed_shard_sample_vs_cpu_oracle"] = match_report(osum, ostat, got_s, got_t)
+                # the reference of the whole-shard rates is itself measured against the oracle at this scale
+                out["parity"]["fp64_gate_kernel_sample_vs_cpu_oracle"] = match_report(osum, ostat, gs[:, :m], gt[:m])
         if not args.no_parity:
             # BASELINE configs[1]: 1 k reference-faithful samples (seed=i stream, CSV wind) against the CPU oracle
             pl = flatten.generate_parameter_samples(sampling.DEFAULT_UNCERTAINTY, 1000)

@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--n", type=int, default=4000)
     ap.add_argument("--ref-samples", type=int, default=48)
     ap.add_argument("--jobs", type=int, default=8)
+    ap.add_argument("--n-large", type=int, default=60000, help="size of the FMA-build comparison at the scale of bench.py's oracle sample")
     args = ap.parse_args()
     t0 = time.time()
     cfg, hb = set_r(args.n)
@@ -160,6 +161,11 @@ def main():
     r = compare(base, fma_oracle()(cfg, hb, args.jobs))
     out["oracle_fma_contracted_build"] = {"flags": "-ffp-contract=fast -mfma (same source, same inputs)", **r}
     print(f"fma build: match {r['match_rate']:.5f} bit-identical {r['bit_identical_apogee']:.3f} median err {r['median_apogee_err']:.3g}", flush=True)
+    if args.n_large > args.n:   # the same comparison at the scale of the bench's oracle sample: what "all of them" means there
+        cfg_l, hb_l = set_r(args.n_large)
+        r = compare(orc.run_batch(cfg_l, hb_l, threads=args.jobs), fma_oracle()(cfg_l, hb_l, args.jobs))
+        out["oracle_fma_contracted_build_large"] = {"n": args.n_large, **r}
+        print(f"fma build, n = {args.n_large}: match {r['match_rate']:.6f} ({len(r['differing_ids'])} differ)  ({time.time() - t0:.0f} s)", flush=True)
     # ---- (c) the Python reference against itself
     if args.ref_samples > 0:
         from multiprocessing import Pool

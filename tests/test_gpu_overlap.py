@@ -140,8 +140,9 @@ def run_gpu(engine, cfg, hb, prec, flags=0):
 
 def test_f64_fast_cfg2_set_r_match_rate(engine, oracle):
     """BASELINE configs[1] (1 k reference-faithful samples) with the fp64 throughput build against the CPU
-    oracle: the reference's apogee_altitude (global argmax) within 0.1 % on >= 99 % of the samples, the
-    first-descent apogee on all of them, same end reason on >= 99 % (measured 99.7 / 100 / 99.7 %)."""
+    oracle: the reference's apogee_altitude (global argmax) within 0.1 %, the first-descent apogee and the end reason
+    on EVERY sample (round 3: 99.7 %; round 4 hands the blow-ups to the reference-order kernel, ERPL_HANDOFF, and
+    tests/golden/sensitivity.json shows that a mere change of rounding pattern keeps 4000 / 4000 outcomes)."""
     hb = mc_batch("liquid", 1000)
     cfg = H.make_config("liquid")
     summ, status = run_gpu(engine, cfg, hb, _abi.PREC_F64_FAST)
@@ -151,7 +152,8 @@ def test_f64_fast_cfg2_set_r_match_rate(engine, oracle):
     end = np.mean((status & 0xFF) == (ostat & 0xFF))
     print(f"f64_fast Set R: apogee match {np.mean(e_ap <= 1e-3):.4f}, first-apogee match {np.mean(e_fa <= 1e-3):.4f}, "
           f"same end {end:.4f}, median err {np.median(e_ap):.1e}")
-    assert np.mean(e_ap <= 1e-3) >= 0.99 and np.mean(e_fa <= 1e-3) >= 0.999 and end >= 0.99
+    assert np.mean(e_ap <= 1e-3) == 1.0 and np.mean(e_fa <= 1e-3) == 1.0 and end == 1.0
+    assert np.array_equal(summ[_abi.SUM_STEPS], osum[_abi.SUM_STEPS])
     assert np.array_equal(summ[_abi.SUM_RAIL_EXIT_TIME], osum[_abi.SUM_RAIL_EXIT_TIME])
     assert np.max(relerr(summ[_abi.SUM_RAIL_EXIT_SPEED], osum[_abi.SUM_RAIL_EXIT_SPEED])) < 1e-12
 
@@ -178,7 +180,7 @@ def test_f64_fast_full_flight_with_parachute(engine, oracle):
     assert np.array_equal(status & 0xFF, ostat & 0xFF)
     landed = ((ostat & 0xFF) == _abi.END_GROUND) & (osum[_abi.SUM_RANGE] < 1e5)
     assert landed.sum() > 40 and np.all((status[landed] & _abi.ST_CHUTE) != 0)
-    assert np.mean(summ[_abi.SUM_STEPS][landed] == osum[_abi.SUM_STEPS][landed]) >= 0.95
+    assert np.array_equal(summ[_abi.SUM_STEPS][landed], osum[_abi.SUM_STEPS][landed])
     assert np.max(relerr(summ[_abi.SUM_APOGEE_ALT], osum[_abi.SUM_APOGEE_ALT])[landed]) < 1e-9
     assert np.max(relerr(summ[_abi.SUM_RANGE], osum[_abi.SUM_RANGE])[landed]) < 1e-6
 
@@ -208,7 +210,8 @@ def test_f64_fast_nan_trajectories_and_geometry(engine, oracle):
     nanrun = (ostat & 0xFF) == _abi.END_MAX_TIME
     assert nanrun.sum() >= 3
     agree = (status & 0xFF)[nanrun] == _abi.END_MAX_TIME
-    assert agree.mean() >= 0.6      # chaotic samples: most, not all, stay on the oracle's side
+    assert agree.mean() == 1.0      # (round 3: >= 0.6 - the blow-ups now finish in the reference-order kernel)
+    assert np.array_equal(status & 0xFF, ostat & 0xFF)
     idx = np.where(nanrun)[0][agree]
     assert np.array_equal(summ[_abi.SUM_STEPS][idx], osum[_abi.SUM_STEPS][idx])
     assert np.array_equal(summ[_abi.SUM_FLIGHT_TIME][idx], osum[_abi.SUM_FLIGHT_TIME][idx])

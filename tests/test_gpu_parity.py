@@ -83,7 +83,7 @@ def test_fp64_vs_reference_golden(engine, oracle, name):
             else:
                 assert status[i] & _abi.ST_NAN
         # and the oracle agrees on how every trajectory ended
-        assert np.mean((status & 0xFF) == (ostat & 0xFF)) >= 0.97
+        assert np.array_equal(status & 0xFF, ostat & 0xFF)
 
 
 # ------------------------------------------------------------------ vs oracle, BASELINE config 2
@@ -102,8 +102,11 @@ def test_cfg2_set_r_1k_fp64_match_rate(engine, oracle):
           f"median err {np.median(e_ap):.2e}/{np.median(e_fa):.2e}, "
           f"same end reason {np.mean((status & 0xFF) == (ostat & 0xFF)):.4f}, "
           f"same step count {np.mean(summ[_abi.SUM_STEPS] == osum[_abi.SUM_STEPS]):.4f}")
-    assert rate_ap >= 0.99 and rate_fa >= 0.99
-    assert np.mean((status & 0xFF) == (ostat & 0xFF)) >= 0.99
+    # the correctness gate: every sample (tests/golden/sensitivity.json - the same source with another rounding pattern
+    # keeps 4000 / 4000 outcomes - is what makes "all of them" the right bar)
+    assert rate_ap == 1.0 and rate_fa == 1.0
+    assert np.array_equal(status & 0xFF, ostat & 0xFF)
+    assert np.array_equal(summ[_abi.SUM_STEPS], osum[_abi.SUM_STEPS])
     # rail phase is exact
     assert np.array_equal(summ[_abi.SUM_RAIL_EXIT_TIME], osum[_abi.SUM_RAIL_EXIT_TIME])
     assert np.max(relerr(summ[_abi.SUM_RAIL_EXIT_SPEED], osum[_abi.SUM_RAIL_EXIT_SPEED])) < 1e-12
@@ -434,8 +437,8 @@ def test_full_size_batch_properties(engine, oracle, precision):
         ea = relerr(summ[_abi.SUM_APOGEE_ALT][pick], osum[_abi.SUM_APOGEE_ALT])
         same_end = (status[pick] & 0xFF) == (ostat & 0xFF)
         print(f"full-size f64_fast subset: apogee match-rate@1e-3 {np.mean(ea <= 1e-3):.4f}, same end reason {np.mean(same_end):.4f}")
-        assert np.mean(ea <= 1e-3) >= 0.99 and np.mean(same_end) >= 0.99
-        assert np.mean(summ[_abi.SUM_STEPS][pick][same_end] == osum[_abi.SUM_STEPS][same_end]) >= 0.99
+        assert np.mean(ea <= 1e-3) == 1.0 and np.mean(same_end) == 1.0       # (blow-ups finish in the reference-order kernel)
+        assert np.array_equal(summ[_abi.SUM_STEPS][pick], osum[_abi.SUM_STEPS])
 
 
 def test_two_and_three_wave_builds_agree_bitwise(engine):
@@ -510,20 +513,20 @@ def test_randomised_configurations(engine, oracle, seed):
     flags = _abi.FLAG_STOP_AT_APOGEE if seed % 3 else 0
     osum, ostat = oracle.run_batch(cfg, hb, flags=flags)
     summ, status = run_gpu(engine, cfg, hb, flags=flags)
-    assert np.mean((status & 0xFF) == (ostat & 0xFF)) >= 0.98
+    assert np.array_equal(status & 0xFF, ostat & 0xFF)
     same = (status == ostat) & np.isfinite(osum[_abi.SUM_RANGE]) & (osum[_abi.SUM_RANGE] < 1e5)
     assert same.sum() >= 0.7 * n
     assert np.array_equal(summ[_abi.SUM_RAIL_EXIT_TIME], osum[_abi.SUM_RAIL_EXIT_TIME])
     for row, tol in ((_abi.SUM_FIRST_APOGEE_ALT, 1e-8), (_abi.SUM_APOGEE_ALT, 1e-8), (_abi.SUM_MAX_SPEED, 1e-8)):
         assert np.max(relerr(summ[row][same], osum[row][same])) < tol, (row, seed)
-    assert np.mean(summ[_abi.SUM_STEPS][same] == osum[_abi.SUM_STEPS][same]) >= 0.98
+    assert np.array_equal(summ[_abi.SUM_STEPS][same], osum[_abi.SUM_STEPS][same])
     sf, tf = run_gpu(engine, cfg, hb, prec=_abi.PREC_F64_FAST, flags=flags)
     same_f = same & (tf == ostat)
-    assert same_f.sum() >= 0.97 * same.sum(), (seed, same_f.sum(), same.sum())
+    assert np.array_equal(tf & 0xFF, ostat & 0xFF) and same_f.sum() == same.sum(), (seed, same_f.sum(), same.sum())
     assert np.array_equal(sf[_abi.SUM_RAIL_EXIT_TIME], osum[_abi.SUM_RAIL_EXIT_TIME])
     for row in (_abi.SUM_FIRST_APOGEE_ALT, _abi.SUM_APOGEE_ALT, _abi.SUM_MAX_SPEED):
         assert np.max(relerr(sf[row][same_f], osum[row][same_f])) < 1e-8, (row, seed)
-    assert np.mean(sf[_abi.SUM_STEPS][same_f] == osum[_abi.SUM_STEPS][same_f]) >= 0.98
+    assert np.array_equal(sf[_abi.SUM_STEPS][same_f], osum[_abi.SUM_STEPS][same_f])
     s32, t32 = run_gpu(engine, cfg, hb, prec=_abi.PREC_F32, flags=flags)
     e = relerr(s32[_abi.SUM_FIRST_APOGEE_ALT][same], osum[_abi.SUM_FIRST_APOGEE_ALT][same])
     print(f"config {seed} ({kind}, K={k}, mach knots {nm}/{nc}): healthy {same.sum()}/{n}, fp32 first-apogee max err {e.max():.2e}")

@@ -276,6 +276,8 @@ def test_g4_sensitivity_record():
     from oracle import oracle as orc
     G = H.load_json("sensitivity.json")
     assert G["n"] >= 2000 and G["oracle_fma_contracted_build"]["match_rate"] == 1.0
+    big = G["oracle_fma_contracted_build_large"]       # the same at the scale of bench.py's oracle sample
+    assert big["n"] >= 50000 and big["match_rate"] == 1.0 and big["differing_ids"] == []
     for mode in ("iid", "dry_mass"):
         for eps in ("1e-16", "1e-15", "1e-14", "1e-13"):
             assert G["oracle_perturbed_inputs"][mode][eps]["match_rate"] == 1.0, (mode, eps)

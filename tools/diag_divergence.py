@@ -179,6 +179,139 @@ def analyse(eng, db, tag, lines, max_samples, cap, dt):
             "disagree": int(len(bad)), "disagree_nan_class": int(nan[bad].sum()), "records": records}
 
 
+def host_of(db, idx):
+    """Samples `idx` of a DeviceBatch as a flatten.HostBatch for the CPU oracle."""
+    ix = torch.as_tensor(np.asarray(idx, dtype=np.int64), device=db.ic.device)
+    hb = flatten.HostBatch(len(idx), db.k_wind)
+    hb.ic = np.ascontiguousarray(db.ic.index_select(1, ix).cpu().numpy())
+    hb.rocket = np.ascontiguousarray(db.rocket.index_select(1, ix).cpu().numpy())
+    hb.motor = np.ascontiguousarray(db.motor.index_select(1, ix).cpu().numpy())
+    hb.alt_grid = db.alt_grid.cpu().numpy().astype(np.float64)
+    hb.wind = np.ascontiguousarray(db.wind.index_select(2, ix).double().cpu().numpy())
+    return hb
+
+
+def analyse_vs_oracle(eng, cfg, db, m, lines, max_samples, cap, dt, threads):
+    """The fp64 gate kernel against the CPU oracle on the first m samples: where do two implementations of the SAME
+    operation order part?  (libm differences: device pow / exp / atan2 / sincos against glibc's.)"""
+    from oracle import oracle as orc
+    hb = host_of(db, np.arange(m))
+    osum, ostat = orc.run_batch(cfg, hb, threads=threads)
+    gs, gt = eng.run(sub_batch(db, np.arange(m), _abi.PREC_F64))
+    torch.cuda.synchronize()
+    gs, gt = gs.cpu().numpy(), gt.cpu().numpy()
+    e_ap = relerr(gs[_abi.SUM_APOGEE_ALT], osum[_abi.SUM_APOGEE_ALT])
+    same_end = (gt & 0xFF) == (ostat & 0xFF)
+    bad = np.nonzero((e_ap > 1e-3) | ~same_end)[0]
+    lines.append(f"== gate kernel vs CPU oracle: n = {m}, apogee match {np.mean(e_ap <= 1e-3):.5f}, same end {np.mean(same_end):.5f}, {len(bad)} disagree")
+    pick = bad[:max_samples]
+    if len(pick) == 0:
+        return {"n": m, "disagree": 0}
+    hs = host_of(db, pick)
+    o_s, o_t, o_tr, o_len = orc.run_batch(cfg, hs, threads=threads, traj_ids=list(range(len(pick))), traj_stride=1, traj_cap=cap)
+    sb = sub_batch(db, pick, _abi.PREC_F64)
+    g_s, g_t, g_tr, g_len = fly(eng, sb, _abi.PREC_F64, cap)
+    recs = []
+    for j, i in enumerate(pick):
+        mm = int(min(g_len[j], o_len[j]))
+        G, O = g_tr[j, :mm, 1:], o_tr[j, :mm, 1:]
+        kc = klass(G) != klass(O)
+        step_class = int(np.argmax(kc.any(axis=1))) if kc.any() else -1
+        with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+            rel = np.where((G == O) | (np.isnan(G) & np.isnan(O)), 0.0, np.abs(G - O) / np.maximum(np.abs(O), 1e-300))
+            rel = np.where(np.isnan(rel), np.inf, rel)
+        worst = rel.max(axis=1)
+        first = {thr: (int(np.nonzero(worst > thr)[0][0]) if (worst > thr).any() else -1) for thr in (1e-12, 1e-9, 1e-6, 1e-3)}
+        lines.append(f"-- sample {i}: oracle apogee {osum[0, i]:.9g} end {ostat[i] & 0xFF} steps {int(osum[_abi.SUM_STEPS, i])} | "
+                     f"gate apogee {gs[0, i]:.9g} end {gt[i] & 0xFF} steps {int(gs[_abi.SUM_STEPS, i])}")
+        lines.append(f"   first rel>1e-12 @ {first[1e-12]}, >1e-9 @ {first[1e-9]}, >1e-6 @ {first[1e-6]}, >1e-3 @ {first[1e-3]}, class diff @ {step_class}")
+        for st in sorted({s for s in (step_class - 2, step_class - 1, step_class) if s >= 0}):
+            lines.append(f"   step {st}: oracle {fmt(O[st])}")
+            lines.append(f"   step {st}: gate   {fmt(G[st])}")
+        rec = {"sample": int(i), "first_class_difference_step": step_class, "first": {str(k): v for k, v in first.items()}}
+        # replay the RK4 stages of the step before the class difference from the ORACLE's state with both RHS
+        if step_class > 0:
+            one = host_of(db, [i])
+            y0, t0 = O[step_class - 1].copy(), float(o_tr[j, step_class - 1, 0])
+            sb1 = sub_batch(db, [i], _abi.PREC_F64)
+            ys, ch_o, ch_g = y0.copy(), 0, np.array([False])
+            for stage in range(4):
+                ts = t0 + (0.0 if stage == 0 else (dt if stage == 3 else 0.5 * dt))
+                k_o, ch_o = orc.rhs(cfg, one, ts, ys, ch_o)
+                k_g, ch_g = rhs(eng, sb1, _abi.PREC_F64, np.array([ts]), ys[:, None], ch_g)
+                k_g = k_g[:, 0]
+                with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+                    r = np.where((k_o == k_g) | (np.isnan(k_o) & np.isnan(k_g)), 0.0, np.abs(k_o - k_g) / np.maximum(np.abs(k_o), 1e-300))
+                dc = klass(k_o) != klass(k_g)
+                lines.append(f"   replay stage {stage + 1}: max rel diff of dy {np.nanmax(np.where(np.isinf(r), np.nan, r)):.3g}" +
+                             (f", CLASS differs in {[NAMES[k] for k in np.nonzero(dc)[0]]}" if dc.any() else ""))
+                if dc.any() or stage == 3:
+                    lines.append(f"     stage state {fmt(ys)}")
+                    lines.append(f"     dy oracle   {fmt(k_o)}")
+                    lines.append(f"     dy gate     {fmt(k_g)}")
+                if dc.any():
+                    rec["rhs_replay"] = {"stage": stage + 1, "components": [NAMES[k] for k in np.nonzero(dc)[0]],
+                                         "stage_state": ys.tolist(), "dy_oracle": k_o.tolist(), "dy_gate": k_g.tolist()}
+                    break
+                adv = dt if stage == 2 else 0.5 * dt
+                with np.errstate(all="ignore"):
+                    ys = y0 + adv * k_o
+            # the same step from the GATE's own state with the ORACLE's RHS and a NumPy RK4 combination (the reference's
+            # expression, simulator.py:217-224): does the difference sit in the state (sensitivity) or in the kernel?
+            def full_step(y_start, use_gate):
+                ys, ch_o, ch_g = y_start.copy(), 0, np.array([False])
+                ks = []
+                for stage in range(4):
+                    ts = t0 + (0.0 if stage == 0 else (dt if stage == 3 else 0.5 * dt))
+                    if use_gate:
+                        k, ch_g = rhs(eng, sb1, _abi.PREC_F64, np.array([ts]), ys[:, None], ch_g)
+                        k = k[:, 0]
+                    else:
+                        k, ch_o = orc.rhs(cfg, one, ts, ys, ch_o)
+                    ks.append(k)
+                    with np.errstate(all="ignore"):
+                        ys = y_start + (dt if stage == 2 else 0.5 * dt) * k
+                with np.errstate(all="ignore"):
+                    yn = y_start + (dt / 6.0) * (((ks[0] + 2 * ks[1]) + 2 * ks[2]) + ks[3])
+                return yn
+            for label, y_start in (("oracle state", O[step_class - 1]), ("gate state  ", G[step_class - 1])):
+                for use_gate in (False, True):
+                    yn = full_step(y_start, use_gate)
+                    lines.append(f"   host RK4 from {label} with {'gate RHS  ' if use_gate else 'oracle RHS'}: {fmt(yn[:6])}")
+            # three steps with the parachute latch carried along (it is part of the state, simulator.py:366-369)
+            for use_gate in (False, True):
+                k0 = max(step_class - 3, 0)
+                y, chs = (G if use_gate else O)[k0].copy(), (np.array([False]) if use_gate else 0)
+                for kk in range(k0, step_class):
+                    tk = float((g_tr if use_gate else o_tr)[j, kk, 0])
+                    ys, ksl = y.copy(), []
+                    for stage in range(4):
+                        ts = tk + (0.0 if stage == 0 else (dt if stage == 3 else 0.5 * dt))
+                        if use_gate:
+                            k, chs = rhs(eng, sb1, _abi.PREC_F64, np.array([ts]), ys[:, None], chs)
+                            k = k[:, 0]
+                        else:
+                            k, chs = orc.rhs(cfg, one, ts, ys, chs)
+                        ksl.append(k)
+                        with np.errstate(all="ignore"):
+                            ys = y + (dt if stage == 2 else 0.5 * dt) * k
+                    with np.errstate(all="ignore"):
+                        y = y + (dt / 6.0) * (((ksl[0] + 2 * ksl[1]) + 2 * ksl[2]) + ksl[3])
+                        nrm = np.sqrt(((y[6] * y[6] + y[7] * y[7]) + y[8] * y[8]) + y[9] * y[9])
+                        if nrm > 1e-12:
+                            y[6:10] = y[6:10] / nrm
+                        else:
+                            y[6:10] = [1.0, 0.0, 0.0, 0.0]
+                    lines.append(f"   host steps with {'gate RHS  ' if use_gate else 'oracle RHS'} -> step {kk + 1}: {fmt(y[:6])} latch {int(np.asarray(chs).ravel()[0])}")
+            lines.append(f"   recorded next state: oracle {fmt(O[step_class][:6])}")
+            lines.append(f"   recorded next state: gate   {fmt(G[step_class][:6])}")
+            d01 = G[step_class - 1] - O[step_class - 1]
+            with np.errstate(all="ignore"):
+                lines.append(f"   rel diff of the two states before the step: {fmt(np.abs(d01) / np.maximum(np.abs(O[step_class - 1]), 1e-300))}")
+        recs.append(rec)
+    return {"n": m, "apogee_match": float(np.mean(e_ap <= 1e-3)), "disagree": int(len(bad)), "records": recs}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=131072)
@@ -186,6 +319,8 @@ def main():
     ap.add_argument("--cap", type=int, default=12000)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "diverge"))
     ap.add_argument("--skip-set-r", action="store_true")
+    ap.add_argument("--vs-oracle", type=int, default=0, help="gate kernel vs CPU oracle on the first N samples of the shard instead")
+    ap.add_argument("--threads", type=int, default=16)
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     dev = torch.device("cuda", 0)
@@ -196,8 +331,11 @@ def main():
     dt = min(float(cfg.dt_initial), 0.005)
     lines, report = [], {}
     db = sampling.synthetic_dispersions(args.n, rocket, motor, wm, IC, dev, precision=_abi.PREC_F64, seed=1234, engine=eng)
-    report["set_s"] = analyse(eng, db, "Set S (bench shard)", lines, args.max_samples, args.cap, dt)
-    if not args.skip_set_r:
+    if args.vs_oracle > 0:
+        report["gate_vs_oracle"] = analyse_vs_oracle(eng, cfg, db, args.vs_oracle, lines, args.max_samples, args.cap, dt, args.threads)
+    else:
+        report["set_s"] = analyse(eng, db, "Set S (bench shard)", lines, args.max_samples, args.cap, dt)
+    if not args.skip_set_r and args.vs_oracle == 0:
         pl = flatten.generate_parameter_samples(sampling.DEFAULT_UNCERTAINTY, 4000)
         hbr = flatten.dispersed_batch(rocket, motor, wm, IC, pl, CSV_ALT, CSV_WIND)
         dbr = DeviceBatch.from_host(hbr, dev, _abi.PREC_F64)
