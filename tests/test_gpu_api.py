@@ -81,12 +81,17 @@ def test_simulate_flight_matches_reference(key, kind, wind):
             assert np.max(np.abs(got_d[r] - gd[r]) / scale) < 1e-5, r
 
 
-def test_run_monte_carlo_example_config():
+@pytest.mark.parametrize("precision", [None, "f64"])
+def test_run_monte_carlo_example_config(precision):
     """example.py's Monte Carlo (CSV base profile) with 32 samples: the reference yields
-    1 valid / 31 outliers; per-sample scalars match the golden run."""
+    1 valid / 31 outliers; per-sample scalars match the golden run - with the default build
+    (f64_fast since round 4) and with the reference-order kernel."""
     idx, arr = H.load_flights("flights_mc")
     gold = {e["key"][3]: e["summary"] for e in idx if e["key"][:3] == ["liquid", "csv", "seed_i"]}
     mc = E.MonteCarloAnalyzer(E.Rocket(), E.LiquidMotor(), E.StandardAtmosphere(), E.WindModel(), verbose=False)
+    assert mc.precision == "f64_fast"
+    if precision:
+        mc.precision = precision
     mc.base_altitude_profile, mc.base_wind_profile = H.CSV_ALT, H.CSV_WIND
     out = mc.run_monte_carlo(dict(H.EXAMPLE_IC), n_samples=32)
     assert out["n_samples"] + out["n_outliers"] == 32 and out["n_failed"] == 0
@@ -97,7 +102,7 @@ def test_run_monte_carlo_example_config():
     for i, s in gold.items():
         r = allr[i]
         assert r["rail_exit_time"] == s["rail_exit_time"]
-        assert r["n_steps"] == s["n_steps"] or abs(r["n_steps"] - s["n_steps"]) <= 1
+        assert r["n_steps"] == s["n_steps"]
         if np.isfinite(s["apogee_altitude"]):
             assert rel(r["apogee_altitude"], s["apogee_altitude"]) < 1e-5, i
         else:

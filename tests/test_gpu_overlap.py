@@ -649,3 +649,47 @@ def test_soak_every_overlapped_batch_equals_run_batch():
             assert bad == 0, (precision, bad, total)
     finally:
         eng.close()
+
+
+def test_f64_fast_capture_continues_across_the_hand_over(engine, oracle):
+    """Trajectory capture of DIVERGING samples in the fp64 throughput build: the records of a sample start in the
+    throughput kernel and continue - same buffer, same stride phase - in the reference-order kernel the lane is handed
+    to when its speed passes 1e6 m/s (ERPL_HANDOFF).  Every-step capture against the CPU oracle: same number of records,
+    exact time stamps, states to 1e-6 up to the blow-up and class-equal (inf / NaN) beyond, identical summaries with
+    and without capture."""
+    hb = mc_batch("liquid", 48)                       # Set R recipe: every sample diverges (SURVEY fact 5)
+    cfg = H.make_config("liquid")
+    from erpl_monte_carlo_sim_amd.engine import DeviceBatch
+    engine.set_config(cfg)
+    db = DeviceBatch.from_host(hb, engine.device, _abi.PREC_F64_FAST)
+    ids = list(range(0, 48, 3))
+    cap = 4000
+    s1, t1, traj, tlen = engine.run(db, traj_ids=ids, traj_stride=1, traj_cap=cap)
+    s0, t0 = engine.run(db)
+    torch.cuda.synchronize()
+    # (the capture build is another specialisation of the same source - run-time wind / motor switches - and
+    # -ffp-contract=fast fuses a few products differently in it: on diverging samples the summaries agree to the
+    # rounding level times the samples' own error amplification, not bit for bit; outcomes and step counts are the same)
+    a, b = s0.cpu().numpy(), s1.cpu().numpy()
+    assert torch.equal(t0, t1) and np.array_equal(a[_abi.SUM_STEPS], b[_abi.SUM_STEPS])
+    assert np.max(relerr(b[_abi.SUM_FIRST_APOGEE_ALT], a[_abi.SUM_FIRST_APOGEE_ALT])) < 1e-9
+    assert np.max(relerr(b[_abi.SUM_APOGEE_ALT], a[_abi.SUM_APOGEE_ALT])) < 1e-5
+    osum, ostat, otraj, otlen = oracle.run_batch(cfg, hb, traj_ids=ids, traj_stride=1, traj_cap=cap)
+    assert np.array_equal(t1.cpu().numpy() & 0xFF, ostat & 0xFF)
+    traj, tlen = traj.cpu().numpy(), tlen.cpu().numpy()
+    n_beyond = 0
+    for m, i in enumerate(ids):
+        assert tlen[m] == otlen[m], i
+        k = int(min(tlen[m], cap))
+        assert np.array_equal(traj[m, :k, 0], otraj[m, :k, 0]), i          # time stamps are exact
+        G, O = traj[m, :k, 1:], otraj[m, :k, 1:]
+        with np.errstate(over="ignore", invalid="ignore"):
+            speed = np.sqrt(np.sum(O[:, 3:6] ** 2, axis=1))
+        calm = np.isfinite(speed) & (speed < 1e3)
+        assert calm.sum() > 1500
+        assert np.max(np.abs(G[calm] - O[calm]) / np.maximum(np.abs(O[calm]), 1e-6)) < 1e-6, i
+        beyond = ~(np.isfinite(speed) & (speed < 1e6))                    # records written by the reference-order kernel
+        n_beyond += int(beyond.sum())
+        cls = lambda a: np.where(np.isnan(a), 3, np.where(np.isposinf(a), 1, np.where(np.isneginf(a), 2, 0)))   # noqa: E731
+        assert np.array_equal(cls(G[beyond]), cls(O[beyond])), i
+    assert n_beyond >= len(ids)                      # every captured sample crossed the hand-over
