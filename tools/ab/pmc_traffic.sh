@@ -11,7 +11,8 @@ for c in ("FETCH_SIZE","WRITE_SIZE"):
     tot=collections.Counter(); n=collections.Counter()
     for f in glob.glob(f"gpurun_out/{tag}_{c}/**/*counter_collection.csv",recursive=True):
         for r in csv.DictReader(open(f)):
-            k="rail" if "erpl_rail" in r["Kernel_Name"] else ("flight" if "erpl_flight" in r["Kernel_Name"] else None)
+            nm=r["Kernel_Name"]
+            k="rail" if "erpl_rail" in nm else ("sweep_f64" if "erpl_flight_f64<" in nm or "erpl_flight_f64I" in nm else ("flight" if "erpl_flight" in nm else None))
             if k: tot[k]+=float(r["Counter_Value"]); n[k]+=1
-    print(c, "flight KB per pass: %.0f"%(tot["flight"]/max(n["rail"],1)), "(dispatches", n["flight"], "passes", n["rail"],")")
+    print(c, "KB per pass: flight_f64f %.0f, hand-over sweep (erpl_flight_f64) %.0f, rail %.0f"%(tot["flight"]/max(n["rail"],1), tot["sweep_f64"]/max(n["rail"],1), tot["rail"]/max(n["rail"],1)), "(dispatches", n["flight"], n["sweep_f64"], "passes", n["rail"],")")
 PY

@@ -34,6 +34,8 @@ def pmc(sub):
     for k in tot:
         kern, counter = k.split(".")
         rail = kern.replace("erpl_flight_", "erpl_rail_") + "." + counter
+        if rail not in cnt and kern == "erpl_flight_f64":      # the hand-over sweep of the f64_fast passes (no gate leg in this run)
+            rail = "erpl_rail_f64f." + counter
         passes[k] = cnt.get(rail, cnt[k])
     return {k: tot[k] / passes[k] for k in sorted(tot)}, (max(passes.values()) if passes else 0)
 
@@ -74,6 +76,10 @@ traffic = {"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) 
            "note": "FETCH_SIZE on gfx950 reads 1/2 of a wide coalesced stream (MI355X_MICROARCH.md HBM section), so the read side is doubled; our loads are 4- and 8-byte-per-lane, for which the guide calls the counter uncalibrated: the corrected figure is an upper bound, the raw one a lower bound. The written bytes are 12 scattered 8-byte summary rows per sample, each costing a 32/64-byte write transaction, plus the rail kernel's resume records."}
 for name, suf in (("f32", "f32"), ("f64_fast", "f64f")):
     fk = fe.get(f"erpl_flight_{suf}.FETCH_SIZE", 0.0); wk = wr.get(f"erpl_flight_{suf}.WRITE_SIZE", 0.0)
+    if name == "f64_fast":      # + the sweep of its hand-over queue by the reference-order kernel (part of every pass)
+        sf, sw = fe.get("erpl_flight_f64.FETCH_SIZE", 0.0), wr.get("erpl_flight_f64.WRITE_SIZE", 0.0)
+        traffic.setdefault("f64_fast_handoff_sweep", {"kernel": "erpl_flight_f64<..,2>", "fetch_size_kb_raw": sf, "write_size_kb": sw})
+        fk, wk = fk + sf, wk + sw
     rf = fe.get(f"erpl_rail_{suf}.FETCH_SIZE", 0.0); rw = wr.get(f"erpl_rail_{suf}.WRITE_SIZE", 0.0)
     traffic[name] = {"kernel": f"erpl_flight_{suf}", "fetch_size_kb_raw": fk, "write_size_kb": wk, "rail_fetch_size_kb_raw": rf,
                      "rail_write_size_kb": rw, "traffic_bytes_per_launch": (2.0 * fk + wk) * 1024.0,
