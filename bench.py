@@ -485,11 +485,11 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
         # (FETCH_SIZE / WRITE_SIZE need the profiler, they cannot be read from inside this process)
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r3_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r4_hbm_traffic.json")
         if os.path.exists(tpath) and args.workload == "set_s" and n == 131072:
             tj = json.load(open(tpath)).get(precision)
             if tj:
-                traffic, traffic_src = tj.get("traffic_bytes_per_launch"), "profiles/r3_hbm_traffic.json (rocprofv3 --pmc passes of this command)"
+                traffic, traffic_src = tj.get("traffic_bytes_per_launch"), "profiles/r4_hbm_traffic.json (rocprofv3 --pmc passes of this command)"
         st = L["status"].cpu().numpy()
         steps_col = L["summary"][_abi.SUM_STEPS].cpu().numpy()
         return {
@@ -510,7 +510,7 @@ def main():
                 "kernel": "erpl_flight_" + {"f32": "f32", "f64": "f64", "f64_fast": "f64f"}[precision],
                 "algorithmic_flops_per_step": FLOPS_PER_STEP, "rk4_steps_per_launch": L["phys_steps"],
                 "launch_duration_ms": per_launch_ms,
-                "timeline": "profiles/r3_bench_timeline.json (rocprofv3 --kernel-trace of this command: union of the erpl_flight dispatch intervals / passes)",
+                "timeline": "profiles/r4_bench_timeline.json (rocprofv3 --kernel-trace of this command: union of the erpl_flight dispatch intervals / passes)",
                 "per_dispatch": {"duration_ms": fl, "achieved": dispatch_tf, "frac": dispatch_tf / peak,
                                  "note": "what rocprofv3 --kernel-trace reports per dispatch; dispatches overlap"},
                 "note": "non-MFMA vector-ALU bound (SURVEY 8d); peak = vector rate of the dtype",

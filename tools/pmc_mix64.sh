@@ -13,12 +13,14 @@ tag = sys.argv[1]
 c = collections.Counter(); n = collections.Counter()
 for f in glob.glob(f'gpurun_out/pmc_mix_{tag}_?/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'erpl_flight' in r['Kernel_Name']:
-            c[r['Counter_Name']] += float(r['Counter_Value']); n[r['Counter_Name']] += 1
+        if 'erpl_flight' in r['Kernel_Name']:   # (all flight dispatches of a run: main launch + the hand-over sweep of the f64_fast build)
+            c[r['Counter_Name']] += float(r['Counter_Value'])
+        if 'erpl_rail' in r['Kernel_Name']:     # one per run
+            n[r['Counter_Name']] += 1
 it = None
 for l in open(f'gpurun_out/pmc_mix_{tag}_a.log'):
     m = re.search(r'wave_iters=(\d+)', l)
     if m: it = int(m.group(1))
-print('wave_iters', it, 'launches', dict(n))
+print('wave_iters', it, 'runs', dict(n))
 for k in sorted(c): print(f'{k:28s} {c[k]/n[k]/it:10.1f} per wave-step')
 PY
