@@ -481,6 +481,8 @@ def main():
         dispatch_tf = L["phys_steps"] * FLOPS_PER_STEP / (fl * 1e-3) / 1e12
         es = 4 if L["prec"] == _abi.PREC_F32 else 8
         algo_bytes = (L["db"].input_bytes() + 2 * n * (14 * es + 8 + 4) + n * (_abi.SUMMARY_DIM * 8 + 4))
+        if precision == "f64_fast":      # + the hand-over record of (nearly) every diverging sample, written once and read once
+            algo_bytes += 2 * n * (20 * 8 + 5 * 8 + 6 * 4)
         hbm_gbps = algo_bytes / (per_launch_ms * 1e-3) / 1e9
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
         # (FETCH_SIZE / WRITE_SIZE need the profiler, they cannot be read from inside this process)

@@ -151,12 +151,17 @@ def test_run_monte_carlo_fp32_and_synthetic_wind():
     assert np.all((status & 0xFF) <= _abi.END_COAST)
 
 
-def test_trajectory_split_does_not_change_summaries():
+@pytest.mark.parametrize("precision", ["f64", "f64_fast"])
+def test_trajectory_split_does_not_change_summaries(precision):
     """run_monte_carlo integrates the samples that carry a trajectory (the first n_trajectories) in a
-    small capture batch and the rest through the specialised build: same bits as one batch."""
+    small capture batch and the rest through the specialised build.  The reference-order kernel gives the same bits
+    either way; in the fp64 throughput build (the default) the capture instantiation fuses a few products differently
+    (-ffp-contract=fast), so there the outcomes and step counts are the same and the scalars agree to the rounding
+    level times the sample's own error amplification."""
     res = {}
     for n_traj in (0, 5, 40):
         mc = E.MonteCarloAnalyzer(E.Rocket(), E.LiquidMotor(), E.StandardAtmosphere(), E.WindModel(), verbose=False)
+        mc.precision = precision
         mc.base_altitude_profile, mc.base_wind_profile = H.CSV_ALT, H.CSV_WIND
         mc.n_trajectories = n_traj
         params = mc._generate_parameter_samples(40)
@@ -166,8 +171,16 @@ def test_trajectory_split_does_not_change_summaries():
         if traj is not None:
             assert len(traj[0]) == n_traj
     for n_traj in (5, 40):
-        assert np.array_equal(res[0][0], res[n_traj][0], equal_nan=True)
         assert np.array_equal(res[0][1], res[n_traj][1])
+        if precision == "f64":
+            assert np.array_equal(res[0][0], res[n_traj][0], equal_nan=True)
+        else:
+            a, b = res[0][0], res[n_traj][0]
+            assert np.array_equal(a[_abi.SUM_STEPS], b[_abi.SUM_STEPS])
+            for row, tol in ((_abi.SUM_FIRST_APOGEE_ALT, 1e-9), (_abi.SUM_APOGEE_ALT, 1e-5), (_abi.SUM_RAIL_EXIT_SPEED, 1e-13)):
+                same = (a[row] == b[row]) | (np.isnan(a[row]) & np.isnan(b[row]))
+                with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+                    assert np.all(same | (np.abs(a[row] - b[row]) <= tol * np.abs(a[row]))), row
 
 
 def test_user_subclass_overriding_model_method_is_refused():

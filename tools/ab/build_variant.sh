@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../../erpl_monte_carlo_sim_amd/csrc"
 T=$1; shift
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I../../include -ffp-contract=fast -fno-slp-vectorize"
-SCHED="-mllvm -amdgpu-sched-strategy=max-memory-clause"
+SCHED="-mllvm -amdgpu-sched-strategy=iterative-maxocc"
 for a in "$@"; do [ "$a" = "-nosched" ] && SCHED=""; done
 ARGS=(); for a in "$@"; do [ "$a" != "-nosched" ] && ARGS+=("$a"); done
 /opt/rocm/bin/hipcc $FL $SCHED "${ARGS[@]}" -c erpl_k64f.hip -o /tmp/k64f_$T.o 2>/dev/null
