@@ -186,8 +186,9 @@ def host_of(db, idx):
     hb.ic = np.ascontiguousarray(db.ic.index_select(1, ix).cpu().numpy())
     hb.rocket = np.ascontiguousarray(db.rocket.index_select(1, ix).cpu().numpy())
     hb.motor = np.ascontiguousarray(db.motor.index_select(1, ix).cpu().numpy())
-    hb.alt_grid = db.alt_grid.cpu().numpy().astype(np.float64)
-    hb.wind = np.ascontiguousarray(db.wind.index_select(2, ix).double().cpu().numpy())
+    if db.k_wind:
+        hb.alt_grid = db.alt_grid.cpu().numpy().astype(np.float64)
+        hb.wind = np.ascontiguousarray(db.wind.index_select(2, ix).double().cpu().numpy())
     return hb
 
 
@@ -321,23 +322,29 @@ def main():
     ap.add_argument("--skip-set-r", action="store_true")
     ap.add_argument("--vs-oracle", type=int, default=0, help="gate kernel vs CPU oracle on the first N samples of the shard instead")
     ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--motor", default="liquid", choices=["liquid", "solid"])
+    ap.add_argument("--wind", default="syn", choices=["syn", "csv", "none"], help="Set S wind: synthetic K=100, CSV base K=6, or none")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     dev = torch.device("cuda", 0)
-    rocket, motor, atm, wm = models.Rocket(), models.LiquidMotor(), models.StandardAtmosphere(), models.WindModel()
+    rocket, atm, wm = models.Rocket(), models.StandardAtmosphere(), models.WindModel()
+    motor = models.SolidMotor() if args.motor == "solid" else models.LiquidMotor()
     cfg = flatten.config_from_objects(rocket, motor, atm)
     eng = TrajectoryEngine(dev, lib_path=os.environ.get("ERPL_LIB"))
     eng.set_config(cfg)
     dt = min(float(cfg.dt_initial), 0.005)
     lines, report = [], {}
-    db = sampling.synthetic_dispersions(args.n, rocket, motor, wm, IC, dev, precision=_abi.PREC_F64, seed=1234, engine=eng)
+    kw = dict(base_altitude_profile=CSV_ALT, base_wind_profile=CSV_WIND) if args.wind == "csv" else {}
+    db = sampling.synthetic_dispersions(args.n, rocket, motor, wm, IC, dev, precision=_abi.PREC_F64, seed=1234, engine=eng, **kw)
+    if args.wind == "none":
+        db = DeviceBatch(db.ic, db.rocket, db.motor, None, None, _abi.PREC_F64)
     if args.vs_oracle > 0:
         report["gate_vs_oracle"] = analyse_vs_oracle(eng, cfg, db, args.vs_oracle, lines, args.max_samples, args.cap, dt, args.threads)
     else:
-        report["set_s"] = analyse(eng, db, "Set S (bench shard)", lines, args.max_samples, args.cap, dt)
+        report["set_s"] = analyse(eng, db, f"Set S ({args.motor} motor, wind {args.wind})", lines, args.max_samples, args.cap, dt)
     if not args.skip_set_r and args.vs_oracle == 0:
         pl = flatten.generate_parameter_samples(sampling.DEFAULT_UNCERTAINTY, 4000)
-        hbr = flatten.dispersed_batch(rocket, motor, wm, IC, pl, CSV_ALT, CSV_WIND)
+        hbr = flatten.dispersed_batch(rocket, motor, wm, IC, pl, *((CSV_ALT, CSV_WIND) if args.wind != "none" else (None, None)))
         dbr = DeviceBatch.from_host(hbr, dev, _abi.PREC_F64)
         report["set_r"] = analyse(eng, dbr, "Set R (cfg 2 recipe, 4000 samples)", lines, args.max_samples, args.cap, dt)
     with open(os.path.join(args.out, "report.txt"), "w") as f:
