@@ -4,6 +4,9 @@
 // fp64 parity with the reference on the chaotic samples at a fraction of the cost
 // of the reference-order gate kernel (erpl_k64.hip).  Round 3: two waves per SIMD (<= 256 registers
 // per lane: lane state, wind interval and table records in LDS - ERPL_TWO_WAVE in erpl_kernels.inc).
+// Round 4: lanes whose speed passes 1e6 m/s are handed to the reference-order kernel (ERPL_HANDOFF): which
+// intermediate of a blow-up's last steps turns inf and which NaN decides how the reference's flight ends, and only
+// the reference's own operation order reproduces that.
 #define ERPL_REAL double
 #define ERPL_FAITHFUL 0
 #define ERPL_FAST_F32 0

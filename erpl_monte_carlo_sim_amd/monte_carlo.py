@@ -204,12 +204,12 @@ class MonteCarloAnalyzer:
         statistics run on the device (`analysis.device_statistics`).  Returns the statistics part of
         the analysis dict plus the gathered tensors; no per-sample dicts.
 
-        precision: "f64_fast" (default) keeps the reference's `apogee_altitude` - the global argmax over all
-        steps, simulator.py:488-490 - within 0.1 % on 99.9 % of reference-faithful samples, and with it the
-        outlier filter and the statistics; "f32" is ~4x faster but on diverging samples only its
-        `first_apogee_altitude` is within 0.1 % (its `apogee_altitude` on ~17 %, its end reason on ~52 %:
-        DESIGN.md section 5), so n_outliers and the statistics differ from the reference's; "f64" is the
-        reference-order gate kernel."""
+        precision: "f64_fast" (default) gives the reference's `apogee_altitude` - the global argmax over all
+        steps, simulator.py:488-490 - end reason and step count on every sample of the parity sets (its blow-ups
+        finish in the reference-order kernel), and with them the reference's outlier filter and statistics;
+        "f32" is ~2.7x faster but on diverging samples only its `first_apogee_altitude` is within 0.1 % (its
+        `apogee_altitude` on ~17 %, its end reason on ~52 %: DESIGN.md section 5), so n_outliers and the
+        statistics differ from the reference's; "f64" runs everything in the reference-order gate kernel."""
         from . import sampling
         eng = shared_engine(self.device)
         eng.set_config(self._config())
