@@ -515,7 +515,11 @@ def main():
                 "timeline": "profiles/r4_bench_timeline.json (rocprofv3 --kernel-trace of this command: union of the erpl_flight dispatch intervals / passes)",
                 "per_dispatch": {"duration_ms": fl, "achieved": dispatch_tf, "frac": dispatch_tf / peak,
                                  "note": "what rocprofv3 --kernel-trace reports per dispatch; dispatches overlap"},
-                "note": "non-MFMA vector-ALU bound (SURVEY 8d); peak = vector rate of the dtype",
+                "note": "non-MFMA vector-ALU bound (SURVEY 8d); peak = vector rate of the dtype at the 2.4 GHz peak engine clock",
+                "sustained_peak_measured": ({"value": 67.9, "unit": "TFLOP/s", "clock_ghz": 2.19,
+                                             "source": "profiles/r4_ubench_clock.txt: a pure v_fma_f64 stream, 4 waves per SIMD; the chip clocks "
+                                                       "at 2.19-2.27 GHz under fp64 load", "frac_of_it": achieved_tf / 67.9}
+                                            if precision != "f32" else None),
                 "hbm": {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                         "frac": hbm_gbps / PEAK_HBM_GBPS, "algorithmic_bytes_per_launch": algo_bytes},
             },
