@@ -326,3 +326,18 @@ def test_device_batch_refuses_tables_of_the_wrong_shape():
             (None, torch.zeros(k, 3, n, dtype=torch.float64), _abi.PREC_F64)):
         with pytest.raises(ValueError):
             DeviceBatch(ic, rk, mt, bad_alt, bad_wind, prec)
+
+
+def test_parameter_arrays_in_parallel_blocks_equal_one_block(monkeypatch):
+    """Round 4: at 10^5+ samples the per-sample dispersion streams are drawn and scaled in blocks by a few Python
+    workers (flatten.generate_parameter_arrays); the values must be those of the single-block path, bit for bit."""
+    from erpl_monte_carlo_sim_amd import sampling
+    n = 5 * 4096 + 17
+    monkeypatch.setattr(flatten, "_PARAM_CHUNK", 4096)          # 6 blocks, the last one ragged
+    monkeypatch.setattr(flatten, "host_workers", lambda: 3)
+    a = flatten.generate_parameter_arrays(sampling.DEFAULT_UNCERTAINTY, n)
+    monkeypatch.setattr(flatten, "_PARAM_CHUNK", 10 ** 9)
+    b = flatten.generate_parameter_arrays(sampling.DEFAULT_UNCERTAINTY, n)
+    assert a.keys() == b.keys()
+    for k in a:
+        assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), k
