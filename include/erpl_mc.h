@@ -60,8 +60,13 @@ enum { ERPL_MOTOR_LIQUID = 0, ERPL_MOTOR_SOLID = 1 };
  *   ERPL_PREC_F64       fp64 in the reference's operation order (IEEE division, libm-grade pow/exp/atan2/sin/cos,
  *                       no FMA contraction): the correctness gate, tracks the CPU reference to ~1e-13 per call
  *   ERPL_PREC_F64_FAST  fp64 arithmetic on the short formulation of the fp32 kernel (one reciprocal per
- *                       denominator, interval-record atmosphere, FMA): keeps the reference's apogee on the
- *                       chaotic samples too at several times the speed of the gate
+ *                       denominator, interval-record atmosphere, FMA) for as long as a sample is of physical size;
+ *                       a sample whose speed passes 1e6 m/s (the reference's model blows up on every sample with
+ *                       sideslip) is finished by the ERPL_PREC_F64 kernel in a sweep launch behind the
+ *                       batch, because WHICH intermediate of a blow-up's last steps turns inf and which NaN decides
+ *                       how the reference's flight ends (simulator.py:216, :238-242) and only the reference's own
+ *                       operation order reproduces it.  The reference's outcome (apogee within 0.1 %, end reason,
+ *                       step count) on every sample of the parity sets, at four times the speed of the gate
  *   ERPL_PREC_F32       fp32 state and RHS (time stays fp64): highest throughput; only the first-descent
  *                       apogee of a diverging sample is within 0.1 % of the reference */
 enum { ERPL_PREC_F64 = 0, ERPL_PREC_F32 = 1, ERPL_PREC_F64_FAST = 2 };
