@@ -26,6 +26,7 @@ PRECISIONS = {"f64": PREC_F64, "f32": PREC_F32, "f64_fast": PREC_F64_FAST}
 MAX_OVERLAP = 8
 DBG_ATMOSPHERE, DBG_AERO, DBG_RHS = 0, 1, 2
 FLAG_STOP_AT_APOGEE = 1
+FLAG_CAPTURE_POSITION_ONLY = 2
 
 # rows of the summary
 (SUM_APOGEE_ALT, SUM_APOGEE_TIME, SUM_FIRST_APOGEE_ALT, SUM_FIRST_APOGEE_TIME, SUM_RANGE,

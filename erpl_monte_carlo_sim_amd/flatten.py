@@ -283,6 +283,7 @@ def legacy_streams(seeds, ops, threads=0, by_output=False):
     every seed: float64 [n, len(ops)], or [len(ops), n] with by_output=True."""
     import ctypes as C
     seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+    threads = threads if threads > 0 else host_cores()
     code = np.frombuffer(ops.encode(), dtype=np.uint8)
     code = np.ascontiguousarray(np.where(code == ord("g"), _abi.RS_GAUSS, _abi.RS_DOUBLE).astype(np.uint8))
     out = np.empty((code.size, seeds.size) if by_output else (seeds.size, code.size), dtype=np.float64)
@@ -314,7 +315,7 @@ def generate_parameter_arrays(uncertainty, n_samples, stream="seed_i"):
         def block(a):
             b = min(n_samples, a + _PARAM_CHUNK)
             d = _scale_parameter_draws(u, legacy_streams(np.arange(a, b, dtype=np.uint32), _PARAM_OPS,
-                                                         threads=max(1, host_cores() // workers)))
+                                                         threads=max(1, host_cores() // workers)))   # (host_cores: what the cgroup grants)
             d["random_seed"] = np.arange(a, b, dtype=np.int64)
             return d
         with ThreadPoolExecutor(workers) as ex:
@@ -331,12 +332,26 @@ _PARAM_CHUNK = 65536
 
 
 def host_cores():
-    """CPU threads this process may use (affinity mask)."""
+    """CPU threads this process may actually use: min(affinity mask, cgroup cpu quota) - a container often shows the
+    host's 256 cores and grants 16."""
     import os
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        n = max(1, len(os.sched_getaffinity(0)))
     except AttributeError:
-        return max(1, os.cpu_count() or 1)
+        n = max(1, os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = max(1, min(n, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return n
 
 
 def host_workers():
@@ -389,6 +404,7 @@ def legacy_wind_profiles(wind_model, alt, seeds, base=None, speed=None, cdir=Non
     mean wind of (speed, direction) per sample (environment.py:125-200); erpl_mc_legacy_wind_profiles."""
     import ctypes as C
     seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+    threads = threads if threads > 0 else host_cores()
     n, K = seeds.size, len(alt)
     sigma, rho, innov = knot_constants(wind_model, alt)
     f = lambda v: np.ascontiguousarray(v, dtype=np.float64)
@@ -436,14 +452,15 @@ def _ar1_profiles(wind_model, alt, g, mean_u=None, mean_v=None, base=None):
 
 
 def dispersed_batch(rocket, motor, wind_model, base_initial_conditions, params_list,
-                    base_altitude_profile=None, base_wind_profile=None, planar=False):
+                    base_altitude_profile=None, base_wind_profile=None, planar=False, threads=0):
     """Per-sample inputs exactly as MonteCarloAnalyzer._run_single_simulation builds them
     (monte_carlo.py:228-288), for all samples at once: IC + offsets, masses x mass_multiplier, motor
     perturbed from a fresh RandomState(seed) with propellant mass / burn time re-synchronised
     (:258-260), wind from another fresh RandomState(seed) (CSV baseline + AR(1) + uniform offset, or
     the 100-knot synthetic profile).  `planar=True` zeroes every out-of-plane input (Set P, SURVEY
     §8d).  `params_list` is the reference's list of dicts or the dict of arrays of
-    generate_parameter_arrays."""
+    generate_parameter_arrays.  `threads`: host threads of the C generators (0 = all the process may use; callers that
+    prepare several batches side by side share them out)."""
     reject_overrides(wind_model, "wind_model")
     use_base = base_wind_profile is not None and base_altitude_profile is not None
     alt = (np.asarray(base_altitude_profile, dtype=np.float64) if use_base else np.linspace(0, 25000, 100))
@@ -482,13 +499,13 @@ def dispersed_batch(rocket, motor, wind_model, base_initial_conditions, params_l
 
     # motor perturbation from a fresh RandomState(seed) (motor.py:95-125 / :171-186)
     if motor_kind(motor) == _abi.MOTOR_SOLID:
-        g = legacy_streams(seeds, "ggg")   # thrust, burn time, impulse (the last two: drawn, then overwritten/unused)
+        g = legacy_streams(seeds, "ggg", threads=threads)   # thrust, burn time, impulse (the last two: drawn, then overwritten/unused)
         k = 1.0 + motor.thrust_uncertainty * g[:, 0]
         mdot = 4.26 * k
         b.motor[0] = k
         b.motor[1] = motor.nozzle_exit_area * k
     else:
-        g = legacy_streams(seeds, "gg")    # thrust, mass flow
+        g = legacy_streams(seeds, "gg", threads=threads)    # thrust, mass flow
         k = 1.0 + motor.thrust_uncertainty * g[:, 0]
         kf = 1.0 + motor.mass_flow_uncertainty * g[:, 1]
         tv = motor.thrust_vacuum * k
@@ -506,14 +523,14 @@ def dispersed_batch(rocket, motor, wind_model, base_initial_conditions, params_l
     speed, direction = P["wind_speed"], P["wind_direction"]
     cd, sd = np.cos(direction), np.sin(direction)
     if use_base:
-        w = legacy_wind_profiles(wind_model, alt, seeds, base=np.asarray(base_wind_profile, dtype=np.float64))
+        w = legacy_wind_profiles(wind_model, alt, seeds, base=np.asarray(base_wind_profile, dtype=np.float64), threads=threads)
         w[:, 0, :] += speed * cd
         if planar:
             w[:, 1, :] = 0.0
         else:
             w[:, 1, :] += speed * sd
     else:
-        w = legacy_wind_profiles(wind_model, alt, seeds, speed=speed, cdir=cd, sdir=sd)
+        w = legacy_wind_profiles(wind_model, alt, seeds, speed=speed, cdir=cd, sdir=sd, threads=threads)
         if planar:
             w[:, 1, :] = 0.0
     b.wind = w

@@ -86,17 +86,33 @@ class MonteCarloAnalyzer:
         prec = _abi.PRECISIONS[self.precision]
         take = (lambda a, b: {k: v[a:b] for k, v in params.items()}) if isinstance(params, dict) else (lambda a, b: params[a:b])
 
-        def host_batch(a, b):
+        def host_batch(a, b, threads=0):
             return flatten.dispersed_batch(self.rocket, self.motor, self.wind_model, initial_conditions, take(a, b),
-                                           self.base_altitude_profile, self.base_wind_profile)
-        parts, traj = [], None
+                                           self.base_altitude_profile, self.base_wind_profile, threads=threads)
+        parts, traj, capture_inputs = [], None, None
         m = max(0, min(hi, n_traj_global) - lo)   # local samples 0..m-1 are captured
         if m > 0:
             db = DeviceBatch.from_host(host_batch(lo, lo + m), eng.device, prec)
             dt = min(self.dt_initial, 0.005)
             cap = int(np.ceil(self.max_time / dt / self.trajectory_stride)) + 4
             ids = list(range(m))
-            summ, status, tr, tlen = eng.run(db, traj_ids=ids, traj_stride=self.trajectory_stride, traj_cap=cap)
+            # on a stream of its own: the capture build follows a non-finite sample step by step to max_time (it has
+            # records to write), 0.6 s for one wave - and erpl_mc_submit_batch starts a batch behind everything that is
+            # on the caller's stream, so on the current stream it held up every chunk below (round 4: 1.5 -> 0.9 s at 10^6)
+            cur = torch.cuda.current_stream(eng.device)
+            capture_stream = torch.cuda.Stream(eng.device)
+            capture_stream.wait_stream(cur)           # the upload above
+            with torch.cuda.stream(capture_stream):   # (its output buffers are allocated and pre-filled on that stream too)
+                summ, status, tr, tlen = eng.run(db, traj_ids=ids, traj_stride=self.trajectory_stride, traj_cap=cap,
+                                                 flags=_abi.FLAG_CAPTURE_POSITION_ONLY)   # 'trajectory' = time, altitude, position
+            for t_ in (summ, status, tr, tlen):
+                t_.record_stream(cur)                 # consumed on the current stream, behind the wait_stream below
+            # the inputs were allocated on the current stream and are read on the other one until the capture ends: they must
+            # not go back to the allocator before (the chunk loop below would otherwise hand their memory to the next upload)
+            capture_inputs = db
+            for t_ in (db.ic, db.rocket, db.motor, db.alt_grid, db.wind):
+                if t_ is not None:
+                    t_.record_stream(capture_stream)
             traj = (ids, tr, tlen)
             parts.append((summ, status))
         inflight = []    # (ticket, inputs): the inputs must outlive their batch (it runs on the library's own streams)
@@ -128,7 +144,7 @@ class MonteCarloAnalyzer:
             # validation and the upload (335 MB of pageable memory per chunk: 70 ms at the 4.6 GB/s such a copy gets) in
             # the worker too: on the default stream of the engine's device, before the submission that follows it there
             with torch.cuda.device(eng.device):
-                return DeviceBatch.from_host(host_batch(a, b), eng.device, prec)
+                return DeviceBatch.from_host(host_batch(a, b, threads=max(1, flatten.host_cores() // workers)), eng.device, prec)
         with ThreadPoolExecutor(workers) as pool:
             todo = iter(chunks)
             ready = collections.deque()
@@ -148,6 +164,9 @@ class MonteCarloAnalyzer:
         if inflight:
             eng.wait()
             retire(-1)
+        if m > 0:
+            torch.cuda.current_stream(eng.device).wait_stream(capture_stream)
+            del capture_inputs
         if len(parts) == 1:
             return parts[0][0], parts[0][1], traj
         return torch.cat([p[0] for p in parts], dim=1), torch.cat([p[1] for p in parts]), traj

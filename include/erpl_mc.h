@@ -73,8 +73,14 @@ enum { ERPL_PREC_F64 = 0, ERPL_PREC_F32 = 1, ERPL_PREC_F64_FAST = 2 };
 
 /* erpl_batch.flags */
 enum {
-  ERPL_FLAG_STOP_AT_APOGEE = 1 /* extension (BASELINE config 2 "to apogee"): end a trajectory at the
+  ERPL_FLAG_STOP_AT_APOGEE = 1, /* extension (BASELINE config 2 "to apogee"): end a trajectory at the
                                   first post-step state with z>1000 and vz<0 (simulator.py:247) */
+  ERPL_FLAG_CAPTURE_POSITION_ONLY = 2 /* trajectory capture (erpl_out.traj*) whose records are read for time and position only
+                                  (the 'trajectory' of MonteCarloAnalyzer's results: monte_carlo.py:298-302): a sample whose
+                                  position has turned non-finite for good - nothing the reference's loop can observe changes
+                                  any more, SURVEY fact 9 - is fast-forwarded to max_time like in a batch without capture;
+                                  its remaining records carry the exact time stamps and the state as it was then (the
+                                  quaternion / angular-velocity / propellant columns are not advanced).  Summaries unchanged. */
 };
 
 /* rows of the per-sample summary, double [ERPL_SUMMARY_DIM][n] */

@@ -693,3 +693,46 @@ def test_f64_fast_capture_continues_across_the_hand_over(engine, oracle):
         cls = lambda a: np.where(np.isnan(a), 3, np.where(np.isposinf(a), 1, np.where(np.isneginf(a), 2, 0)))   # noqa: E731
         assert np.array_equal(cls(G[beyond]), cls(O[beyond])), i
     assert n_beyond >= len(ids)                      # every captured sample crossed the hand-over
+
+
+@pytest.mark.parametrize("precision", ["f64", "f64_fast"])
+def test_capture_fast_forward_of_non_finite_samples(engine, oracle, precision):
+    """ERPL_FLAG_CAPTURE_POSITION_ONLY (the capture batch of MonteCarloAnalyzer.run_monte_carlo): a captured sample whose
+    position has turned non-finite for good is fast-forwarded to max_time instead of being integrated step by step - 57 000
+    steps for one wave, which used to be most of a run_monte_carlo call.  Same summaries and statuses as without the flag,
+    the same number of records with the same (exactly accumulated) time stamps and the same position columns as the
+    step-by-step capture and as the CPU oracle's; and it is faster."""
+    import time
+    pl = flatten.generate_parameter_samples(H.UNCERTAINTY, 32, stream="seed_42")      # ids 17 and 24 turn non-finite
+    hb = flatten.dispersed_batch(models.Rocket(), models.LiquidMotor(), models.WindModel(), H.EXAMPLE_IC, pl,
+                                 base_altitude_profile=H.CSV_ALT, base_wind_profile=H.CSV_WIND)
+    cfg = H.make_config("liquid")
+    from erpl_monte_carlo_sim_amd.engine import DeviceBatch
+    engine.set_config(cfg)
+    db = DeviceBatch.from_host(hb, engine.device, _abi.PRECISIONS[precision])
+    ids = list(range(32))
+    stride, cap = 20, 3100
+    out, secs = {}, {}
+    for flags in (0, _abi.FLAG_CAPTURE_POSITION_ONLY):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        s, t, traj, tlen = engine.run(db, flags=flags, traj_ids=ids, traj_stride=stride, traj_cap=cap)
+        torch.cuda.synchronize()
+        secs[flags] = time.time() - t0
+        out[flags] = (s.cpu().numpy(), t.cpu().numpy(), traj.cpu().numpy(), tlen.cpu().numpy())
+    a, b = out[0], out[_abi.FLAG_CAPTURE_POSITION_ONLY]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0], equal_nan=True)
+    assert np.array_equal(a[3], b[3])
+    osum, ostat, otraj, otlen = oracle.run_batch(cfg, hb, traj_ids=ids, traj_stride=stride, traj_cap=cap)
+    assert np.array_equal(b[3], otlen)
+    nonfinite = np.nonzero((b[1] & _abi.ST_NAN) != 0)[0]
+    assert len(nonfinite) >= 2
+    for i in ids:
+        k = int(b[3][i])
+        assert np.array_equal(b[2][i, :k, 0], a[2][i, :k, 0]) and np.array_equal(b[2][i, :k, 0], otraj[i, :k, 0]), i   # time stamps
+        assert np.array_equal(b[2][i, :k, 1:4], a[2][i, :k, 1:4], equal_nan=True), i                                    # position
+        if i in nonfinite:
+            assert k > 2900 and np.isnan(b[2][i, k - 1, 3])                  # records all the way to max_time
+    print(f"{precision}: capture of 32 samples ({len(nonfinite)} non-finite): {secs[0] * 1e3:.0f} ms step by step, "
+          f"{secs[_abi.FLAG_CAPTURE_POSITION_ONLY] * 1e3:.0f} ms fast-forwarded")
+    assert secs[_abi.FLAG_CAPTURE_POSITION_ONLY] < 0.5 * secs[0]
