@@ -229,8 +229,9 @@ def api_end_to_end(device, rocket, motor, atm, wm, n=1000000):
             shape = {"raised": str(e)[:60]}
         el = (t2 if "n_valid" in shape else time.perf_counter()) - t1
         out["run_monte_carlo_" + precision] = {"n_samples": m, "total_time": el, "simulations_per_second": m / el, **shape}
-    out["note"] = ("run_monte_carlo defaults to precision 'f64' (the reference-order gate kernel); 'f64_fast' is the build for "
-                   "10^5 - 10^7 samples (the same outcomes on every sample of the parity sets, see `parity`)")
+    out["note"] = ("run_monte_carlo defaults to precision 'f64_fast' (the fp64 throughput build; its blow-ups finish in the "
+                   "reference-order kernel: the same outcomes on every sample of the parity sets, see `parity`); 'f64' runs every "
+                   "sample in the reference-order gate kernel")
     return out
 
 
@@ -565,7 +566,7 @@ def main():
         # passes: one lasts ten times longer)
         gate_leg = main_leg if args.precision == "f64" else timed_leg("f64", steps=max(2, min(args.steps, 8)), warmup=min(args.warmup, 2))
         gj = leg_json(gate_leg)
-        out["f64_gate"] = {"note": "the fp64 reference-order kernel (ERPL_PREC_F64), the API default of run_monte_carlo: "
+        out["f64_gate"] = {"note": "the fp64 reference-order kernel (ERPL_PREC_F64; MonteCarloAnalyzer.precision = 'f64'): "
                                    f"{gate_leg['steps']} passes over the same shard through erpl_mc_submit_batch, like the other legs",
                            "value": gj["value"], "unit": gj["unit"], "ms_per_step": gj["ms_per_step"], "steps": gate_leg["steps"],
                            "lane_utilisation": gj["lane_utilisation"], "kernel_ms": gj["kernel_ms"],
