@@ -6,6 +6,10 @@
 
 One "step" = one pass of the hot path (rail kernel + RK4 flight kernel [+ RCCL all-gather of the
 per-sample summaries when N > 1]) over one batch of synthetic dispersions ALREADY RESIDENT in HBM.
+Every pass integrates a DIFFERENT shard (all of them generated on the device before the warm-up; `--shards 1`
+replays one shard, as rounds 1-3 did: cache-warm inputs, identical end times, and shard 0's one 16 029-step
+trajectory as the tail of every pass - DESIGN.md section 3.1).  The first timed pass runs shard 0: parity, end
+reasons and the CPU baseline refer to it.
 Workload at N = 1: 131 072 dispersed samples per GPU (BASELINE configs[2]; x 8 GPUs = the 1 048 576
 samples of configs[3]), LiquidMotor, reference dispersion model (monte_carlo.py:156-179), synthetic
 100-knot wind profile, full reference termination logic.  Weak scaling (default): every rank integrates its
@@ -23,7 +27,7 @@ longest trajectory; the next pass uses the lanes that have already finished).  A
 inside the timed region.
 
 Prints ONE JSON line (rank 0).  `value`, `dtype`, `apogee_match_rate`, `roofline` all describe the SAME
-kernel build (--precision, default f64_fast) on the SAME shard:
+kernel build (--precision, default f64_fast); the match rates are those of shard 0:
   apogee_match_rate  fraction of the shard's samples whose `apogee_altitude` (the reference's global
                 argmax, simulator.py:488-490) is within 0.1 % of the fp64 reference-order gate kernel
                 run on the same inputs (that kernel tracks the CPU oracle on 100 % of the cfg-2 set:
@@ -300,6 +304,8 @@ def main():
     ap.add_argument("--refill", type=int, default=1)
     ap.add_argument("--adopt", type=int, default=-1, help="lane adoption limit (erpl_mc_set_adopt); 0 = off; -1 = library default")
     ap.add_argument("--overlap", type=int, default=-1, help="passes in flight (erpl_mc_set_overlap); 0 = erpl_mc_run_batch on the stream; -1 = library default")
+    ap.add_argument("--shards", type=int, default=0, help="distinct input shards the passes cycle through: 0 = one per timed pass (capped at "
+                    "48 GB of inputs), 1 = every pass replays one resident shard (what rounds 1-3 timed)")
     ap.add_argument("--waves", type=int, default=0, help="fp32 kernel build: 2 or 3 waves per SIMD (0 = library default)")
     ap.add_argument("--chunk", type=int, default=-1, help="steps per launch between compactions (-1 = library default)")
     args = ap.parse_args()
@@ -359,9 +365,25 @@ def main():
     flags = _abi.FLAG_STOP_AT_APOGEE if args.workload == "set_p_apogee" else 0
     csv = args.workload == "csv_chute"
     # one set of samples for every kernel build: fp64 draws, the wind table rounded once for fp32
-    db64 = sampling.synthetic_dispersions(
-        n, rocket, motor, wm, EXAMPLE_IC, device, precision=_abi.PREC_F64, seed=1234 + rank, planar=planar or csv,
-        base_altitude_profile=CSV_ALT if csv else None, base_wind_profile=CSV_WIND if csv else None, engine=eng)
+    shard_cache = {}
+
+    def shard64(j):
+        """Shard j of this rank (fp64 draws, resident in HBM): j = 0 is the shard every parity figure refers to."""
+        if j not in shard_cache:
+            shard_cache[j] = sampling.synthetic_dispersions(
+                n, rocket, motor, wm, EXAMPLE_IC, device, precision=_abi.PREC_F64, seed=1234 + rank + 7919 * j, planar=planar or csv,
+                base_altitude_profile=CSV_ALT if csv else None, base_wind_profile=CSV_WIND if csv else None, engine=eng)
+        return shard_cache[j]
+    db64 = shard64(0)
+
+    def n_shards(steps, depth):
+        """Distinct shards the passes of a leg cycle through (a replayed shard is cache-warm and its lanes
+        end at identical times in every pass): one per timed pass unless --shards says otherwise; fp64 + fp32 copies of
+        the inputs stay under 48 GB; erpl_mc_run_batch legs (--overlap 0) replay one shard (no per-ticket counters)."""
+        if depth <= 0:
+            return 1
+        want = args.shards if args.shards > 0 else steps
+        return max(1, min(want, steps, int(48e9 // (1.5 * db64.input_bytes()))))
     eng.reserve(n)
     side = torch.cuda.Stream(device) if world > 1 else None
 
@@ -370,22 +392,26 @@ def main():
         steps = args.steps if steps is None else steps
         warmup = args.warmup if warmup is None else warmup
         prec = _abi.PRECISIONS[precision]
-        db = as_precision(db64, prec)
         depth = leg_depth(precision)
+        S = n_shards(steps, depth)
+        dbs = [as_precision(shard64(j), prec) for j in range(S)]
+        db = dbs[0]
         if depth > 0:
             eng.set_overlap(depth)
         # every lane of the library owns two workspaces (a lane's next batch starts while the sweeps of its previous one
         # still write results): pass i + depth may run beside pass i, so the output buffers rotate over 2 x depth sets
         # (+ 1 for the gather that still reads one) - a buffer is reused only behind the batch that last wrote it
         nbuf = 2 * max(depth, 1) + (1 if world > 1 else 0)
-        outs = [eng.alloc_outputs(n) for _ in range(nbuf)]
-        last_ticket_of = [0] * nbuf
+        # (set `nbuf` belongs to the FIRST timed pass alone - shard 0, the one the parity figures are about - and is never reused)
+        outs = [eng.alloc_outputs(n) for _ in range(nbuf + 1)]
+        last_ticket_of = [0] * (nbuf + 1)
         gath = []
-        for _ in range(nbuf if world > 1 else 0):
+        for _ in range(nbuf + 1 if world > 1 else 0):
             gdev = "cpu" if gloo_rehearsal else device
             gath.append((torch.empty((world * _abi.SUMMARY_DIM, n), dtype=torch.float64, device=gdev),
                          torch.empty((world * n,), dtype=torch.int32, device=gdev)))
-        pending = [None] * nbuf
+        pending = [None] * (nbuf + 1)
+        tickets = []
 
         def wait_gather(k):
             if pending[k] is not None:
@@ -393,17 +419,20 @@ def main():
                     w.wait()
                 pending[k] = None
 
-        def step(i):
-            k = i % nbuf
+        def step(i, timed=False):
+            k = nbuf if (timed and i == 0) else i % nbuf
+            db_i = dbs[i % S]
             wait_gather(k)  # the gather that last read these output buffers
             s_k, t_k = outs[k]
             if depth > 0:
                 if last_ticket_of[k]:
                     eng.wait(last_ticket_of[k])   # (device-side; a no-op in practice: that batch is 2 x depth passes back)
-                eng.submit(db, flags=flags, summary=s_k, status=t_k)
+                eng.submit(db_i, flags=flags, summary=s_k, status=t_k)
                 last_ticket_of[k] = eng.last_ticket
+                if timed:
+                    tickets.append(eng.last_ticket)
             else:
-                eng.run(db, flags=flags, summary=s_k, status=t_k)
+                eng.run(db_i, flags=flags, summary=s_k, status=t_k)
             if world > 1:
                 # all-gather of the per-sample summaries (monte_carlo.py:76-83) on a side stream that waits
                 # for THIS pass only: RCCL over xGMI overlaps the kernels of the following passes
@@ -422,7 +451,7 @@ def main():
         def drain():
             if depth > 0:
                 eng.wait()          # the current stream waits for every pass in flight
-            for k in range(nbuf):
+            for k in range(nbuf + 1):
                 wait_gather(k)
 
         eng.set_profiling(True)
@@ -437,7 +466,7 @@ def main():
         t0 = time.perf_counter()
         ev0.record()
         for i in range(steps):
-            step(i)
+            step(i, timed=True)
         drain()
         ev1.record()
         torch.cuda.synchronize()
@@ -451,22 +480,26 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo_rehearsal else device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        last = (steps - 1) % nbuf
-        summary, status = outs[last]
+        summary, status = outs[nbuf]     # the first timed pass: shard 0
         if world > 1:  # every rank must hold every rank's summaries: rank-major rows, own block == own results
-            g_s, g_t = gath[last]
+            g_s, g_t = gath[nbuf]
             own = g_s[rank * _abi.SUMMARY_DIM:(rank + 1) * _abi.SUMMARY_DIM].to(summary.device)
             if not bool(((own == summary) | (own.isnan() & summary.isnan())).all()) or \
                     not torch.equal(g_t[rank * n:(rank + 1) * n].to(status.device), status):
                 raise SystemExit("all-gather result does not contain this rank's summaries")
         rail_ms, flight_ms = eng.kernel_ms_history(steps)
-        phys_steps, wave_iters = eng.last_stats()
+        if tickets:      # device counters of every timed pass (the shards differ): mean per launch
+            per_pass = [eng.ticket_stats(t) for t in tickets[-250:]]   # (the library keeps the records of its last 256 tickets)
+            phys_steps = float(np.mean([x[0] for x in per_pass]))
+            wave_iters = float(np.mean([x[1] for x in per_pass]))
+        else:
+            phys_steps, wave_iters = eng.last_stats()
         phys_total = phys_steps
         if world > 1:
             tot = torch.tensor([phys_steps], dtype=torch.float64, device="cpu" if gloo_rehearsal else device)
             dist.all_reduce(tot)
             phys_total = float(tot.item())
-        return {"steps": steps, "precision": precision, "prec": prec, "db": db, "elapsed": elapsed, "gpu_ms": gpu_ms, "depth": depth,
+        return {"steps": steps, "precision": precision, "prec": prec, "db": db, "elapsed": elapsed, "gpu_ms": gpu_ms, "depth": depth, "shards": S,
                 "summary": summary, "status": status, "rail_ms": rail_ms, "flight_ms": flight_ms,
                 "phys_steps": phys_steps, "wave_iters": wave_iters, "phys_total": phys_total}
 
@@ -546,7 +579,10 @@ def main():
                                     f"{'CSV base wind K=6' if csv else 'synthetic wind K=100'}, "
                                     f"rail dt=0.01 + RK4 dt=0.005, "
                                     f"{'to first-descent apogee' if flags else 'full reference termination logic'}",
-                        "samples_per_gpu": n, "precision": args.precision, "passes_in_flight": max(depth, 1), "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                        "samples_per_gpu": n, "precision": args.precision, "passes_in_flight": max(depth, 1),
+                        "distinct_shards": main_leg["shards"],
+                        "shards_note": "every timed pass integrates a DIFFERENT resident shard (seed 1234 + rank + 7919 x pass; --shards 1 replays "
+                                       "one); the parity figures and end_reasons are those of the first timed pass (shard 0); counters are means over the passes", "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                         "lane_adoption": "library default" if args.adopt < 0 else args.adopt,
                         "parallelism": f"sample-shard x{world}" + (" + RCCL all-gather of [16,n] summaries overlapped with the following passes" if world > 1 else ""),
                     }})

@@ -92,7 +92,7 @@ RS_GAUSS, RS_DOUBLE = 0, 1   # erpl_mc_legacy_random_streams ops
 
 EXPORTS = ("erpl_mc_abi_version", "erpl_mc_last_error", "erpl_mc_create", "erpl_mc_destroy",
            "erpl_mc_set_config", "erpl_mc_reserve", "erpl_mc_run_batch", "erpl_mc_set_launch",
-           "erpl_mc_last_stats", "erpl_mc_set_profiling", "erpl_mc_last_kernel_ms",
+           "erpl_mc_last_stats", "erpl_mc_ticket_stats", "erpl_mc_set_profiling", "erpl_mc_last_kernel_ms",
            "erpl_mc_kernel_ms_history", "erpl_mc_debug_counters", "erpl_mc_extract_histories", "erpl_mc_set_chunk",
            "erpl_mc_legacy_random_streams", "erpl_mc_legacy_wind_profiles", "erpl_mc_set_waves_per_simd",
            "erpl_mc_set_overlap", "erpl_mc_submit_batch", "erpl_mc_wait_batch", "erpl_mc_synchronize",
@@ -153,6 +153,7 @@ def load_library(path=None):
     lib.erpl_mc_get_overlap.restype = C.c_int
     lib.erpl_mc_set_waves_per_simd.argtypes = [C.c_void_p, C.c_int]
     lib.erpl_mc_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.erpl_mc_ticket_stats.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.erpl_mc_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.erpl_mc_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.erpl_mc_kernel_ms_history.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),

@@ -1044,4 +1044,18 @@ int erpl_mc_last_stats(erpl_ctx* c, double* total_steps, double* wave_iterations
   return ERPL_OK;
 }
 
+/* Device counters of ONE submitted batch (its record in the ticket ring): waits for that batch alone. */
+int erpl_mc_ticket_stats(erpl_ctx* c, int64_t ticket, double* total_steps, double* wave_iterations) {
+  if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
+  HIP_TRY(hipSetDevice(c->device));
+  const int ri = ring_index(c, ticket);
+  if (ri < 0) return fail(ERPL_ERR_INVALID, "ticket %lld is not (or no longer) among the last %d submitted batches",
+                          (long long)ticket, (int)ERPL_TICKET_RING);
+  HIP_TRY(hipEventSynchronize(c->ring_done[ri]));
+  if (total_steps) *total_steps = (double)c->ring_counters[4 * ri + 1];
+  if (wave_iterations) *wave_iterations = (double)c->ring_counters[4 * ri + 2];
+  if (c->ring_counters[4 * ri + 3] != 0ull) return report_incomplete(ticket, c->ring_counters[4 * ri + 3]);
+  return ERPL_OK;
+}
+
 }  // extern "C"

@@ -277,3 +277,9 @@ class TrajectoryEngine:
         torch.cuda.synchronize(self.device)
         _abi.check(self.lib, self.lib.erpl_mc_last_stats(self._ctx, C.byref(a), C.byref(b)), "erpl_mc_last_stats")
         return a.value, b.value
+
+    def ticket_stats(self, ticket):
+        """(physics RK4 steps integrated, wave-iterations) of ONE submitted batch (waits for that batch alone)."""
+        a, b = C.c_double(), C.c_double()
+        _abi.check(self.lib, self.lib.erpl_mc_ticket_stats(self._ctx, C.c_int64(ticket), C.byref(a), C.byref(b)), "erpl_mc_ticket_stats")
+        return a.value, b.value

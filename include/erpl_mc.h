@@ -278,6 +278,10 @@ int erpl_mc_set_adopt_spin(erpl_ctx* ctx, int polls);
 /* Diagnostics of the last run_batch on this ctx (after the stream has been synchronised):
  * total RK4 steps integrated over all samples and total wave-iterations executed. */
 int erpl_mc_last_stats(erpl_ctx* ctx, double* total_steps, double* wave_iterations);
+/* The same two counters of ONE batch handed over with erpl_mc_submit_batch, by its ticket (host-blocking for that batch
+ * alone; ERPL_ERR_INVALID once the ticket has left the ring of the last 256 submitted batches, ERPL_ERR_INCOMPLETE as
+ * erpl_mc_check_batch). */
+int erpl_mc_ticket_stats(erpl_ctx* ctx, int64_t ticket, double* total_steps, double* wave_iterations);
 
 /* Per-step diagnostic histories of FlightSimulator._extract_results (simulator.py:496-552) for m
  * stored records traj[m][ERPL_TRAJ_DIM] (as written by erpl_out.traj) of sample `sample` of an
