@@ -471,6 +471,34 @@ def test_tickets_are_waitable_one_by_one_in_any_order(engine, depth):
         engine.set_overlap(3)
 
 
+def test_ticket_stats_are_those_of_the_ticket(engine):
+    """erpl_mc_ticket_stats: the device counters of ONE submitted batch, whichever batches ran beside or after it - the
+    physics step count of a batch is a property of its samples (what bench.py averages over its distinct shards), equal to
+    what erpl_mc_last_stats reports when the batch runs alone; a ticket that was never issued is refused."""
+    engine.set_config(H.make_config("liquid"))
+    dbs = batches(engine, _abi.PREC_F64_FAST, 5, n=3000)
+    alone = []
+    for db in dbs:
+        engine.run(db)
+        alone.append(engine.last_stats()[0])
+    assert len(set(alone)) == len(alone)                 # five different batches
+    engine.set_overlap(3)
+    try:
+        tickets = []
+        for db in dbs:
+            engine.submit(db)
+            tickets.append(engine.last_ticket)
+        for i in (4, 0, 2, 1, 3):                        # any order, the newest first
+            steps, iters = engine.ticket_stats(tickets[i])
+            assert steps == alone[i] and iters > 0, i
+        engine.synchronize()
+        assert engine.ticket_stats(tickets[0])[0] == alone[0]    # still answered afterwards
+        with pytest.raises(_abi.ErplError, match="not .or no longer. among the last"):
+            engine.ticket_stats(tickets[-1] + 1000)
+    finally:
+        engine.set_overlap(3)
+
+
 def test_mixed_traffic_matches_serial_runs(engine):
     """A seeded random mix of everything the lanes support at once: the three kernel builds, batch sizes from one
     sample to 9 000, erpl_mc_submit_batch and erpl_mc_run_batch interleaved on the same context, waits on single
