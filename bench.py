@@ -306,6 +306,7 @@ def main():
     ap.add_argument("--overlap", type=int, default=-1, help="passes in flight (erpl_mc_set_overlap); 0 = erpl_mc_run_batch on the stream; -1 = library default")
     ap.add_argument("--shards", type=int, default=0, help="distinct input shards the passes cycle through: 0 = one per timed pass (capped at "
                     "48 GB of inputs), 1 = every pass replays one resident shard (what rounds 1-3 timed)")
+    ap.add_argument("--short-overlap", type=int, default=-1, help="erpl_mc_set_short_flight_overlap (-1 = library default: 4; 0 = off)")
     ap.add_argument("--waves", type=int, default=0, help="fp32 kernel build: 2 or 3 waves per SIMD (0 = library default)")
     ap.add_argument("--chunk", type=int, default=-1, help="steps per launch between compactions (-1 = library default)")
     args = ap.parse_args()
@@ -351,6 +352,8 @@ def main():
     eng.set_waves_per_simd(args.waves)
     if args.adopt >= 0:
         eng.set_adopt(args.adopt)
+    if args.short_overlap >= 0:
+        eng.set_short_flight_overlap(args.short_overlap)
     lib_depth = eng.get_overlap()     # 8 when the process has a hardware queue per batch in flight, else 3
 
     def leg_depth(precision):

@@ -97,7 +97,7 @@ EXPORTS = ("erpl_mc_abi_version", "erpl_mc_last_error", "erpl_mc_create", "erpl_
            "erpl_mc_legacy_random_streams", "erpl_mc_legacy_wind_profiles", "erpl_mc_set_waves_per_simd",
            "erpl_mc_set_overlap", "erpl_mc_submit_batch", "erpl_mc_wait_batch", "erpl_mc_synchronize",
            "erpl_mc_debug_eval", "erpl_mc_synth_wind", "erpl_mc_set_adopt", "erpl_mc_get_overlap",
-           "erpl_mc_check_batch", "erpl_mc_set_adopt_spin")
+           "erpl_mc_check_batch", "erpl_mc_set_adopt_spin", "erpl_mc_set_short_flight_overlap")
 
 _lib = None
 

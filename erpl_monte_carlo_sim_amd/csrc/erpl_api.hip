@@ -274,6 +274,7 @@ struct erpl_ctx {
   int adopt_spin = 1 << 22;       // polls of an adopting lane for a claimed record's ready word (erpl_mc_set_adopt_spin)
   int adopt = -1;                 // lane adoption: flying lanes at or below which a wave hands its lanes over; 0 = off; < 0 = by batch
   int chunk = -1;                 // steps per launch between compactions; 0 = one launch; < 0 = by the batches seen so far
+  int short_depth = 4;            // erpl_mc_set_short_flight_overlap
   double seen_mean_steps = 0.0;   // physics RK4 steps per trajectory of the most recent COMPLETED batch
   int64_t seen_seq = 0, batches = 0;
   int waves = 0;   // 0 = choose by batch size
@@ -376,6 +377,20 @@ void fill_common_args(const erpl_ctx* c, const erpl_batch* b, ErplKArgs& a) {
   a.dt_rail = T.dt_rail; a.dt_flight = T.dt_flight; a.max_time = T.max_time;
 }
 
+// Trajectory length is not known in advance: the scheduling choices that depend on it (step chunks, how many batches of
+// short flights start side by side) follow the batches this context has already FINISHED - their device step counter is
+// copied to pinned memory behind every batch.
+constexpr double kLongFlightSteps = 8192.0;
+void note_finished_batches(erpl_ctx* c) {
+  for (int i = 0; i < 2 * ERPL_MAX_OVERLAP; ++i) {
+    ErplSlot& q = c->slot[i];
+    if (q.used && q.seq > c->seen_seq && q.last_n > 0 && hipEventQuery(q.done) == hipSuccess) {
+      c->seen_mean_steps = (double)q.h_counters[1] / (double)q.last_n;
+      c->seen_seq = q.seq;
+    }
+  }
+}
+
 // Rail + flight kernels of one batch through the lane's next set, on stream `st`; `sweep` (or NULL) = the stream
 // the launches behind the main one go to when the batch runs with lane adoption.
 int enqueue_batch(erpl_ctx* c, int lane, const erpl_batch* b, const erpl_out* o, hipStream_t st, int in_flight,
@@ -428,14 +443,8 @@ int enqueue_batch(erpl_ctx* c, int lane, const erpl_batch* b, const erpl_out* o,
   // Results do not depend on the choice (bitwise).
   int chunk_steps = c->chunk;
   if (chunk_steps < 0) {
-    for (int i = 0; i < 2 * ERPL_MAX_OVERLAP; ++i) {
-      ErplSlot& q = c->slot[i];
-      if (q.used && q.seq > c->seen_seq && q.last_n > 0 && hipEventQuery(q.done) == hipSuccess) {
-        c->seen_mean_steps = (double)q.h_counters[1] / (double)q.last_n;
-        c->seen_seq = q.seq;
-      }
-    }
-    chunk_steps = (in_flight >= 2 && o->n_traj == 0 && c->seen_mean_steps >= 8192.0) ? 2048 : 0;
+    note_finished_batches(c);
+    chunk_steps = (in_flight >= 2 && o->n_traj == 0 && c->seen_mean_steps >= kLongFlightSteps) ? 2048 : 0;
   }
   if (chunk_steps > 0 && T.max_time > 0) {
     const double max_steps = ceil(T.max_time / T.dt_flight) + 2.0;
@@ -629,13 +638,26 @@ int erpl_mc_set_overlap(erpl_ctx* c, int depth) {
   return ERPL_OK;
 }
 
+int erpl_mc_set_short_flight_overlap(erpl_ctx* c, int depth) {
+  if (!c) return fail(ERPL_ERR_INVALID, "NULL ctx");
+  if (depth < 0 || depth > ERPL_MAX_OVERLAP) return fail(ERPL_ERR_INVALID, "short-flight overlap must be 0..%d", ERPL_MAX_OVERLAP);
+  c->short_depth = depth;
+  return ERPL_OK;
+}
+
 int erpl_mc_submit_batch(erpl_ctx* c, const erpl_batch* b, const erpl_out* o, void* stream, int64_t* ticket) {
   int rc = check_batch(c, b, o);
   if (rc != ERPL_OK) return rc;
   if (ticket) *ticket = c->submitted;   // an empty batch is complete as soon as its predecessors are
   if (b->n == 0) return ERPL_OK;
   HIP_TRY(hipSetDevice(c->device));
-  const int lane = (int)(c->submitted % c->depth);
+  // Short flights (erpl_mc_set_short_flight_overlap) go round fewer lanes: fewer streams busy at a time
+  int depth = c->depth;
+  if (c->short_depth > 0 && c->short_depth < depth) {
+    note_finished_batches(c);
+    if (c->seen_mean_steps > 0.0 && c->seen_mean_steps < kLongFlightSteps) depth = c->short_depth;
+  }
+  const int lane = (int)(c->submitted % depth);
   if (!c->lane_stream[lane]) HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream[lane], hipStreamNonBlocking));
   // the sweep stream only where lane adoption can come on: a stream takes a hardware queue, and with the HIP default
   // of four a second one per lane would push the main streams onto shared queues
@@ -662,7 +684,7 @@ int erpl_mc_submit_batch(erpl_ctx* c, const erpl_batch* b, const erpl_out* o, vo
     if (c->slot[i].h_counters == &c->ring_counters[4 * ri]) c->slot[i].h_counters = c->slot[i].own_counters;
   memset(&c->ring_counters[4 * ri], 0, 4 * sizeof(unsigned long long));
   c->ring_ticket[ri] = 0;
-  rc = enqueue_batch(c, lane, b, o, c->lane_stream[lane], c->depth, may_adopt ? c->lane_sweep[lane] : nullptr, t_new,
+  rc = enqueue_batch(c, lane, b, o, c->lane_stream[lane], depth, may_adopt ? c->lane_sweep[lane] : nullptr, t_new,
                      &c->ring_counters[4 * ri], c->ring_done[ri]);
   if (rc != ERPL_OK) return rc;
   c->ring_ticket[ri] = t_new;

@@ -129,6 +129,11 @@ class TrajectoryEngine:
         status = torch.empty((n,), dtype=torch.int32, device=self.device)
         return summary, status
 
+    def set_short_flight_overlap(self, depth):
+        """How many batches of short flights start side by side (erpl_mc_set_short_flight_overlap; default 4, 0 = no limit
+        besides set_overlap).  Scheduling only."""
+        _abi.check(self.lib, self.lib.erpl_mc_set_short_flight_overlap(self._ctx, int(depth)), "erpl_mc_set_short_flight_overlap")
+
     def get_overlap(self):
         """Batches `submit()` keeps in flight at once (3, or 8 when the process has the hardware queues for it)."""
         return int(self.lib.erpl_mc_get_overlap(self._ctx))

@@ -223,6 +223,14 @@ int erpl_mc_run_batch(erpl_ctx* ctx, const erpl_batch* batch, const erpl_out* ou
  * the Python package sets 24 on import).  erpl_mc_get_overlap returns the depth in use. */
 #define ERPL_MAX_OVERLAP 8
 int erpl_mc_set_overlap(erpl_ctx* ctx, int depth);
+/* How many batches of SHORT flights are in flight (scheduling only; results do not depend on it, bitwise).  With a hardware
+ * queue per stream up to `depth` batches run beside each other, which pays for long flights (15 k-step flights: 8 in
+ * flight 3 % faster than 4, fp32 7 %) and costs 2-3 % for short ones (2.5 k steps, the dispersed sets whose samples blow
+ * up: 3 to 5 in flight 22.6 ms per 131 072-sample pass, 8 in flight 23.2 - fewer busy streams, not a later start: making
+ * the eighth batch wait for the fourth without taking its stream away changes nothing).  Once the batches this context has
+ * FINISHED averaged fewer than 8192 RK4 steps per trajectory, erpl_mc_submit_batch goes round the first `depth` lanes only.
+ * Default 4; 0 = always all lanes of erpl_mc_set_overlap. */
+int erpl_mc_set_short_flight_overlap(erpl_ctx* ctx, int depth);
 int erpl_mc_get_overlap(erpl_ctx* ctx);
 int erpl_mc_submit_batch(erpl_ctx* ctx, const erpl_batch* batch, const erpl_out* out, void* hip_stream, int64_t* ticket);
 int erpl_mc_wait_batch(erpl_ctx* ctx, int64_t ticket, void* hip_stream);

@@ -254,6 +254,8 @@ def test_bench_two_ranks_on_one_gpu(tmp_path, mode):
     assert d["cpu_baseline"] is None and "f32" in d and d["f32"]["value"] > 0
     # value = the samples of BOTH ranks per second of the slowest rank
     assert d["value"] == pytest.approx(2 * n_rank * 4 / (d["ms_per_step"] * 4e-3), rel=1e-6)
+    # every timed pass integrated a different shard (round 4); the counters are means over the passes' own tickets
+    assert d["config"]["distinct_shards"] == 4 and d["roofline"]["rk4_steps_per_launch"] > 1000 * n_rank
 
 
 def test_bench_gpus_8_on_a_one_gpu_box_fails_clearly():

@@ -471,6 +471,33 @@ def test_tickets_are_waitable_one_by_one_in_any_order(engine, depth):
         engine.set_overlap(3)
 
 
+def test_short_flights_go_round_fewer_lanes_with_the_same_bits(engine):
+    """erpl_mc_set_short_flight_overlap: once the finished batches averaged fewer than 8192 steps per trajectory the
+    submissions go round the first four lanes only (fewer busy streams: 2 % on the bench shard).  Scheduling only: every
+    limit gives the bits of the serial runs, through the switch from "no history yet" to "short flights" as well."""
+    from erpl_monte_carlo_sim_amd.engine import TrajectoryEngine
+    eng = TrajectoryEngine(engine.device)                     # fresh context: no history
+    try:
+        eng.set_config(H.make_config("liquid"))
+        dbs = batches(eng, _abi.PREC_F64_FAST, 6, n=4000)
+        serial = [tuple(x.clone() for x in eng.run(db)) for db in dbs]
+        torch.cuda.synchronize()
+        eng.set_overlap(8)
+        for limit in (4, 0, 2, 8):
+            eng.set_short_flight_overlap(limit)
+            for rep in range(3):                              # 18 submissions per limit: the history is there from the first pass on
+                outs = [eng.submit(db) for db in dbs]
+                eng.wait()
+                torch.cuda.synchronize()
+                for i, (s, t) in enumerate(outs):
+                    assert torch.equal(t, serial[i][1]) and same(s, serial[i][0]), (limit, rep, i)
+        eng.synchronize()
+        with pytest.raises(_abi.ErplError):
+            eng.set_short_flight_overlap(9)
+    finally:
+        eng.close()
+
+
 def test_ticket_stats_are_those_of_the_ticket(engine):
     """erpl_mc_ticket_stats: the device counters of ONE submitted batch, whichever batches ran beside or after it - the
     physics step count of a batch is a property of its samples (what bench.py averages over its distinct shards), equal to
