@@ -7,7 +7,7 @@ C="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I../..
 echo "# hipcc -Rpass-analysis=kernel-resource-usage, gfx950, flags of csrc/Makefile ($(/opt/rocm/bin/hipcc --version | grep -m1 -o 'HIP version.*'))"
 echo "# template arguments of erpl_flight_*: <trajectory capture, specialisation (bit 0 wind table, bit 1 solid motor; n1 = run time), min waves per SIMD>"
 printf "%-46s %5s %5s %5s %8s %6s %10s %10s %8s\n" kernel SGPR VGPR AGPR scratchB waves sgpr_spill vgpr_spill LDS_B
-for u in "k64f -ffp-contract=fast -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-maxocc" "k32 -ffp-contract=fast -fno-slp-vectorize" "k64 -ffp-contract=off"; do
+for u in "k64f -ffp-contract=fast -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-maxocc" "k32 -ffp-contract=fast -fno-slp-vectorize" "k64 -ffp-contract=off -mllvm -amdgpu-sched-strategy=max-ilp"; do
   set -- $u; unit=$1; shift
   /opt/rocm/bin/hipcc $C "$@" erpl_$unit.hip 2>&1 | python3 -c '
 import re,sys
