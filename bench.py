@@ -415,6 +415,7 @@ def main():
                          torch.empty((world * n,), dtype=torch.int32, device=gdev)))
         pending = [None] * (nbuf + 1)
         tickets = []
+        last_writer = {}     # output set -> (timed pass, shard) that wrote it last
 
         def wait_gather(k):
             if pending[k] is not None:
@@ -434,6 +435,7 @@ def main():
                 last_ticket_of[k] = eng.last_ticket
                 if timed:
                     tickets.append(eng.last_ticket)
+                    last_writer[k] = i % S
             else:
                 eng.run(db_i, flags=flags, summary=s_k, status=t_k)
             if world > 1:
@@ -502,7 +504,10 @@ def main():
             tot = torch.tensor([phys_steps], dtype=torch.float64, device="cpu" if gloo_rehearsal else device)
             dist.all_reduce(tot)
             phys_total = float(tot.item())
+        # results of the timed passes that are still in their output sets (a set is reused nbuf passes later): shard -> (summary, status)
+        kept = {j: outs[k] for k, j in last_writer.items()}
         return {"steps": steps, "precision": precision, "prec": prec, "db": db, "elapsed": elapsed, "gpu_ms": gpu_ms, "depth": depth, "shards": S,
+                "kept": kept,
                 "summary": summary, "status": status, "rail_ms": rail_ms, "flight_ms": flight_ms,
                 "phys_steps": phys_steps, "wave_iters": wave_iters, "phys_total": phys_total}
 
@@ -616,6 +621,13 @@ def main():
         rep = match_report(gs, gt, main_leg["summary"].cpu().numpy(), main_leg["status"].cpu().numpy())
         out["apogee_match_rate"] = rep["apogee_match_rate_0p1pct"]
         out["parity"] = {"timed_shard_vs_fp64_gate_kernel": rep}
+        # the other shards both legs still hold the results of (the gate leg runs fewer passes): the same comparison, pooled
+        both = sorted(j for j in set(main_leg["kept"]) & set(gate_leg["kept"]) if j != 0) if gate_leg is not main_leg else []
+        if both:
+            cat = lambda leg, c: np.concatenate([leg["kept"][j][c].cpu().numpy() for j in both], axis=-1)
+            more = match_report(cat(gate_leg, 0), cat(gate_leg, 1), cat(main_leg, 0), cat(main_leg, 1))
+            more["shards"] = both
+            out["parity"]["other_timed_shards_vs_fp64_gate_kernel"] = more
         if second is not None:
             rep2 = match_report(gs, gt, second["summary"].cpu().numpy(), second["status"].cpu().numpy())
             out[second_name]["apogee_match_rate"] = rep2["apogee_match_rate_0p1pct"]
