@@ -82,7 +82,7 @@ def main():
         t_limit = t_next if t_next is not None else (after[0][0] if after else rows[-1][1] + 1)
         fl = [r for r in rows if is_kernel(r[2], "flight", suffix[p]) and t_begin <= r[0] < t_limit]
         # round 4: the fp64 throughput build hands its blow-ups to the reference-order kernel - one more flight dispatch
-        # (erpl_flight_f64<.., 2>, the register-capped instantiation) behind the launches of every pass; part of the pass
+        # (erpl_flight_f64, the gate's own one-wave-per-SIMD instantiation) behind the launches of every pass; part of the pass
         sweep = [r for r in rows if p == "f64_fast" and is_kernel(r[2], "flight", "f64") and t_begin <= r[0] < t_limit]
         fl = sorted(fl + sweep)
         iv = [(s, e) for s, e, *_ in fl]
@@ -97,7 +97,7 @@ def main():
                           "registers": sorted({(r[3], r[4]) for r in fl}), "lds_bytes": sorted({r[5] for r in fl}),
                           "scratch_bytes": sorted({r[6] for r in fl})}
         if sweep:
-            out["legs"][p]["handoff_sweep"] = {"kernel": "erpl_flight_f64 (reference-order kernel, 256-register instantiation)",
+            out["legs"][p]["handoff_sweep"] = {"kernel": "erpl_flight_f64 (reference-order kernel; its waves take a whole SIMD and wait for one: the dispatch lasts, the work is two steps per record)",
                                                "dispatches": len(sweep), "sum_of_dispatch_ms": sum(e - s for s, e, *_ in sweep) / 1e6,
                                                "mean_dispatch_ms": sum(e - s for s, e, *_ in sweep) / 1e6 / len(sweep),
                                                "share_of_flight_dispatch_time": sum(e - s for s, e, *_ in sweep) / tot if tot else None}
