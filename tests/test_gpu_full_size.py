@@ -269,3 +269,32 @@ def test_bench_gpus_8_on_a_one_gpu_box_fails_clearly():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True,
                        text=True, cwd=ROOT, timeout=300)
     assert r.returncode != 0 and f"8 GPUs requested, {torch.cuda.device_count()} visible" in r.stderr, r.stderr[-1500:]
+
+
+def test_bench_line_with_one_replayed_shard_and_with_a_shard_per_pass():
+    """`bench.py` on one GPU at a small size: the default integrates a different resident shard in every timed pass,
+    `--shards 1` replays one (the method of rounds 1-3); either way ONE JSON line with the contract's keys, the roofline of
+    the dominant kernel from the timed passes' own device counters, and the parity block of the first timed pass (shard 0),
+    which both methods run on the same samples: the same match report."""
+    import json
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--samples-per-gpu", "16384",
+            "--cpu-seconds", "1", "--no-cfg5", "--no-api"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    got = {}
+    for name, extra in (("per_pass", []), ("replay", ["--shards", "1"])):
+        r = subprocess.run(base + extra, env=env, capture_output=True, text=True, cwd=ROOT, timeout=600)
+        assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        d = got[name] = json.loads(lines[0])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
+            assert k in d, k
+        assert d["config"]["distinct_shards"] == (3 if name == "per_pass" else 1)
+        assert d["roofline"]["frac"] == pytest.approx(d["roofline"]["achieved"] / d["roofline"]["peak"])
+        assert d["parity"]["timed_shard_vs_fp64_gate_kernel"]["n"] == 16384
+        assert d["parity"]["timed_shard_vs_fp64_gate_kernel"]["same_end_reason"] == 1.0
+    a, b = (got[k]["parity"]["timed_shard_vs_fp64_gate_kernel"] for k in ("per_pass", "replay"))
+    assert a == b                                                   # shard 0 either way
+    assert "other_timed_shards_vs_fp64_gate_kernel" in got["per_pass"]["parity"]
+    assert "other_timed_shards_vs_fp64_gate_kernel" not in got["replay"]["parity"]
